@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference); the fixtures are committed so the
+GPU box never needs the reference.  Three sources, each the reference's own code or data:
+
+  scan.json      site lists from the reference's C++ scanner, compiled from its sources by
+                 oracle/ref_build (-> oracle/_ref/ref_scan):
+                 src/app/hifimeth/eval_kmer_features.cpp:67-126, src/corelib/bam_info.cpp:169-222
+  windows.npz    401x8 windows from the reference's Python training-time assembler
+                 training/sample_dataset.py:84-139 (imported, not copied)
+  cnn_<ctx>.npz  logits of the reference's shipped TorchScript models models/CpG.pt, CHH.pt
+                 (torch.jit.load on CPU).  CHG.pt holds a different checkpoint than CHG.onnx
+                  and is not used.
+
+usage: python tools/make_golden.py [/root/reference]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REF, "training"))
+
+import torch  # noqa: E402
+
+from hifimeth_amd.synth import Read, pack_codes, synth_reads  # noqa: E402
+from oracle import hm_oracle as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+
+
+def make_scan():
+    rng = np.random.default_rng(7)
+    recs = []
+
+    def add(seq, flag=4):
+        recs.append((flag, seq))
+
+    for L, gc in ((1500, 0.36), (1200, 0.5), (1003, 0.7), (64, 0.5), (3, 0.5), (2, 0.5), (1, 0.5)):
+        p = [(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2]
+        add("".join("ACGT"[i] for i in rng.choice(4, L, p=p)))
+    add("CG" * 40)
+    add("C" * 50 + "G" * 50)
+    add("CCGCAGCTGCGGCHHH".replace("H", "A") * 5)
+    add("ACGTNCGNNCCGCANGCTGGGNAAGNTTGCNAACCNGG" * 8)           # N breaks motifs
+    add("".join("ACGT"[i] for i in rng.choice(4, 1100)), flag=16)  # stored as reverse strand
+    add("".join("ACGT"[i] for i in rng.choice(4, 1100)), flag=0)
+    out = O.ref_scan(recs)
+    js = [dict(flag=f, seq=s, **d) for (f, s), d in zip(recs, out)]
+    json.dump(js, open(os.path.join(GOLD, "scan.json"), "w"))
+    print(f"scan.json: {len(js)} records, {sum(len(d['cpg']) + len(d['chg']) + len(d['chh']) for d in js)} sites")
+
+
+def make_windows():
+    import sample_dataset as SD  # the reference's module
+
+    rng = np.random.default_rng(11)
+    reads = [r for r in synth_reads(3, seed=5, median_len=1400, sigma=0.1, frac_wide=0, frac_short=0, frac_missing=0)]
+    # one very short read so that both window ends are clipped at once
+    L = 260
+    codes = rng.choice(4, L).astype(np.uint8)
+    kin = [np.clip(np.rint(rng.gamma(2.0, 12.0, L)), 0, 255).astype(np.uint8) for _ in range(4)]
+    kin[0][:8] = [0, 63, 64, 127, 128, 191, 192, 255]  # all four codec segments incl. boundaries
+    reads.append(Read("short", L, 4, pack_codes(codes), *kin))
+    packs = dict(n_reads=len(reads))
+    all_w, all_s, all_q, all_r = [], [], [], []
+    for ri_, rd in enumerate(reads):
+        fwd = rd.ascii()
+        L = rd.l_qseq
+        codes = np.frombuffer(fwd, np.uint8)
+        lut = np.zeros(256, np.uint8)
+        lut[[65, 67, 71, 84]] = [0, 1, 2, 3]
+        codes = lut[codes]
+        # dataset layout (sample_dataset.py:90-96): seq | fipd | fpw | ripd | rpw, all in FORWARD
+        # coordinates; the BAM tags ri/rp are stored in reverse-strand order (bam_info.cpp:520-548
+        # indexed with L-1-i at eval_kmer_features.cpp:54-60) -> flip them.
+        feats = np.concatenate([codes, rd.fi, rd.fp, rd.ri[::-1], rd.rp[::-1]]).astype(np.uint8)
+        offsets = np.array([(0, 0, L, -1, -1)], dtype=[('offset', np.int64), ('id', np.int32), ('size', np.int32),
+                                                        ('fn', np.int32), ('rn', np.int32)])
+        cg = np.nonzero((codes == 1) | (codes == 2))[0]
+        pick = np.unique(np.concatenate([cg[:6], cg[-6:], rng.choice(cg, 6, replace=False)]))
+        samples = np.array([[0, q, 1] for q in pick], dtype=np.uint64)
+        for i in range(len(pick)):
+            F, _ = SD.assemble_one_sample_features(feats, samples, offsets, 401, i)
+            all_w.append(F.numpy())
+            all_s.append(0 if codes[pick[i]] == 1 else 1)
+            all_q.append(int(pick[i]))
+            all_r.append(ri_)
+        packs[f"seq4_{ri_}"] = rd.seq4
+        packs[f"len_{ri_}"] = np.int32(L)
+        for nm in ("fi", "fp", "ri", "rp"):
+            packs[f"{nm}_{ri_}"] = getattr(rd, nm)
+    packs.update(windows=np.stack(all_w).astype(np.float32), strand=np.array(all_s, np.uint8),
+                 qoff=np.array(all_q, np.int32), read=np.array(all_r, np.int32))
+    np.savez_compressed(os.path.join(GOLD, "windows.npz"), **packs)
+    print(f"windows.npz: {len(all_w)} windows from {len(reads)} reads")
+    # the reference's LUT (float64 divide, then cast) vs the inference path's fp32 divide
+    lut64 = np.array(SD.codev1_to_frame_table, np.float64).astype(np.float32)
+    lut32 = O.codev1_table().astype(np.float32) / np.float32(952)
+    print("  LUT fp64-vs-fp32 divide mismatches:", int((lut64 != lut32).sum()))
+    return np.stack(all_w).astype(np.float32)
+
+
+def make_cnn(wins):
+    rng = np.random.default_rng(13)
+    extra = np.zeros((4, 401, 8), np.float32)          # all-zero window + random windows
+    extra[1:, :, :4] = np.eye(4, dtype=np.float32)[rng.integers(0, 4, (3, 401))]
+    extra[1:, :, 4:] = rng.gamma(2.0, 0.03, (3, 401, 4)).astype(np.float32)
+    x = np.concatenate([wins[:60], extra])
+    report = {}
+    for ctx in ("CpG", "CHH"):
+        m = torch.jit.load(os.path.join(REF, "models", ctx + ".pt"), map_location="cpu")
+        with torch.no_grad():
+            lg = m(torch.from_numpy(x)).numpy().astype(np.float32)
+        np.savez_compressed(os.path.join(GOLD, f"cnn_{ctx}.npz"), windows=x, logits=lg)
+        om = O.Model(os.path.join(ROOT, "hifimeth_amd", "weights", ctx + ".hmw"))
+        d = float(np.abs(om.logits(x) - lg).max())
+        report[ctx + ".pt_vs_oracle_max_dlogit"] = d
+        print(f"cnn_{ctx}.npz: {len(x)} windows, oracle(ONNX weights) vs {ctx}.pt max |dlogit| = {d:.3g}")
+
+    # structural check against the Python definition (training/model_cnn.py) with random weights:
+    # fold its BatchNorms the way the ONNX export did and run the oracle on the folded weights.
+    import model_cnn
+    from hifimeth_amd.onnx_weights import ModelWeights, save_hmw
+    torch.manual_seed(3)
+    net = model_cnn.DNAModNet(401)
+    with torch.no_grad():
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.normal_(0, 0.3)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_(0, 0.2)
+    net.eval()
+    cw, cb = [], []
+    seq = list(net.convs)
+    for i in range(8):
+        conv, bn = seq[3 * i], seq[3 * i + 1]
+        s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
+        cw.append((conv.weight.detach() * s[:, None, None]).numpy())
+        cb.append((bn.bias - bn.running_mean * s).detach().numpy())
+    mw = ModelWeights(13, float(net.bn0.eps), net.bn0.weight.detach().numpy(), net.bn0.bias.detach().numpy(),
+                      net.bn0.running_mean.numpy(), net.bn0.running_var.numpy(), cw, cb,
+                      net.fc1.weight.detach().numpy(), net.fc1.bias.detach().numpy(),
+                      net.fc2.weight.detach().numpy(), net.fc2.bias.detach().numpy())
+    tmp = "/tmp/_dnamodnet_random.hmw"
+    save_hmw(mw, tmp)
+    with torch.no_grad():
+        want = net(torch.from_numpy(x)).numpy()
+    got = O.Model(tmp).logits(x)
+    d = float(np.abs(want - got).max())
+    report["DNAModNet_random_vs_oracle_max_dlogit"] = d
+    print(f"DNAModNet(random weights, BN folded) vs oracle max |dlogit| = {d:.3g} (logit scale {np.abs(want).max():.3g})")
+    os.remove(tmp)
+    json.dump(report, open(os.path.join(GOLD, "cnn_report.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    if not O.ref_scan_available():
+        raise SystemExit("build oracle/_ref first: make -C oracle")
+    make_scan()
+    w = make_windows()
+    make_cnn(w)
