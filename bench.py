@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- cytosine sites/sec (CpG+CHG+CHH) of the hifimeth `call` hot path on MI355X.
+
+One "step" = one pass of the hot path (site scan -> kinetics windows -> CNN -> probabilities)
+over one batch of synthetic HiFi reads that is already resident in HBM (BASELINE.json configs[2]
+statistics: Arabidopsis-like GC 0.36, read length log-normal around 15 kb, all three contexts).
+Each rank drives one GPU with its own batch (reads are independent: no data-path collective,
+weak scaling); `value` is the whole-job sites/s = sum of sites over ranks * steps / max time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per site (BASELINE.md section 2 / SURVEY.md 8d), 2 FLOP per MAC
+MAC_TOTAL = {0: 11148800, 1: 11148800, 2: 11440640}
+# share of the dominant kernel (front: conv1..conv4)
+MAC_FRONT = {0: 197 * 128 * 88 + 99 * 128 * 384 + 50 * 128 * 384 + 25 * 96 * 384,
+             1: 197 * 128 * 88 + 99 * 128 * 384 + 50 * 128 * 384 + 25 * 96 * 384,
+             2: 196 * 128 * 104 + 98 * 128 * 384 + 49 * 128 * 384 + 25 * 96 * 384}
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
+
+
+def cpu_baseline(reads, budget_s=15.0):
+    """The CPU oracle (port of the reference path) timed on this node's host cores, bounded sample."""
+    from oracle import hm_oracle as O
+    O.build()
+    cores = os.cpu_count() or 1
+    models = [O.Model(os.path.join(ROOT, "hifimeth_amd", "weights", n + ".hmw")) for n in ("CpG", "CHG", "CHH")]
+    t0 = time.perf_counter()
+    sites = 0
+    nreads = 0
+    for rd in reads:
+        if not rd.has_kinetics() or rd.l_qseq < 1000:
+            continue
+        sites += len(O.call_read(models, 7, rd, nthreads=cores)["qoff"])
+        nreads += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": sites / dt, "unit": "sites/s", "cores": cores, "kind": "port",
+            "sample": f"first {nreads} reads of the rank-0 batch ({sites} sites, all contexts), "
+                      f"oracle/hm_oracle.c fp32, OpenMP over sites, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=96, help="reads per GPU batch (~15 kb each)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from hifimeth_amd import MethylationCaller
+    from hifimeth_amd.synth import synth_reads
+
+    reads = synth_reads(args.reads, seed=20250220 + rank, gc=0.36)
+    mc = MethylationCaller(device=local_rank, timing=True)
+    mc.submit_all(reads)
+    mc.upload()          # inputs resident in HBM before the timed region
+    mc.sync()
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        mc.run()
+        mc.sync()
+    mc.timing(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mc.run()
+    mc.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    sites_ctx = [mc.num_sites(c) for c in range(3)]
+    sites_step = sum(sites_ctx)
+    tm = mc.timing()
+    bases = sum(r.l_qseq for r in reads if r.has_kinetics() and r.l_qseq >= 1000)
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_max = float(t.item())
+        s = torch.tensor([float(sites_step)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        sites_all = float(s.item())
+    else:
+        dt_max, sites_all = dt, float(sites_step)
+
+    if rank == 0:
+        front_ms = sum(tm["front_ms"])
+        front_launches = sum(tm["front_launches"])
+        flop_front = sum(2.0 * MAC_FRONT[c] * tm["front_sites"][c] for c in range(3))
+        achieved = flop_front / (front_ms * 1e-3) / 1e12 if front_ms > 0 else 0.0
+        gpu_ms = {k: tm[k] for k in ("prep_ms", "scan_ms", "emit_ms")}
+        gpu_ms["front_ms"] = front_ms
+        gpu_ms["tail_ms"] = sum(tm["tail_ms"])
+        out = {
+            "metric": "cytosine sites/sec (CpG+CHG+CHH)",
+            "value": sites_all * args.steps / dt_max,
+            "unit": "sites/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "synthetic 30x-style HiFi reads (GC 0.36, ~15 kb log-normal, codev1 kinetics), "
+                                   "all three contexts, batch resident in HBM; BASELINE.json configs[2] statistics",
+                       "reads_per_gpu": args.reads, "bases_per_gpu": int(bases), "sites_per_gpu_step": int(sites_step),
+                       "sites_by_context": {"CpG": sites_ctx[0], "CHG": sites_ctx[1], "CHH": sites_ctx[2]},
+                       "parallelism": f"read-sharded x{world}, no collective"},
+            "roofline": {"bound": "mfma", "kernel": "front_kernel (window+bn0+conv1..conv4, fp32 MFMA 16x16x4)",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "avg_launch_ms": front_ms / front_launches if front_launches else None,
+                         "launches": front_launches, "traffic": None},
+            "device_ms_timed_region": gpu_ms,
+            "effective_tflops_all_layers": sum(2.0 * MAC_TOTAL[c] * sites_ctx[c] for c in range(3)) * args.steps / dt_max / 1e12,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(reads)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    mc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

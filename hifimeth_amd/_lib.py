@@ -1,0 +1,78 @@
+"""ctypes loader of libhifimeth_hip.so (the C ABI of include/hifimeth_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded this module raises,
+and hm_create() fails when no gfx950 device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhifimeth_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+WEIGHTS_DIR = os.path.join(HERE, "weights")
+
+
+class hm_call_t(C.Structure):
+    _fields_ = [("read_id", C.c_int32), ("qoff", C.c_int32), ("strand", C.c_uint8), ("ctx", C.c_uint8),
+                ("scaled_prob", C.c_uint8), ("reserved", C.c_uint8), ("p", C.c_float)]
+
+
+class hm_timing_t(C.Structure):
+    _fields_ = [("prep_ms", C.c_double), ("scan_ms", C.c_double), ("emit_ms", C.c_double), ("window_ms", C.c_double),
+                ("front_ms", C.c_double * 3), ("tail_ms", C.c_double * 3),
+                ("prep_launches", C.c_int64), ("scan_launches", C.c_int64), ("emit_launches", C.c_int64),
+                ("window_launches", C.c_int64), ("front_launches", C.c_int64 * 3), ("tail_launches", C.c_int64 * 3),
+                ("front_sites", C.c_int64 * 3), ("window_sites", C.c_int64)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hifimeth_amd has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, cp = C.c_void_p, C.c_int32, C.c_int64, C.c_char_p
+    sig = {
+        "hm_create": (C.c_int, [C.POINTER(vp), cp, C.c_int, C.c_int]),
+        "hm_destroy": (None, [vp]),
+        "hm_last_error": (cp, [vp]),
+        "hm_set_option": (C.c_int, [vp, cp, i64]),
+        "hm_submit_read": (C.c_int, [vp, i32, i32, i32, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int]),
+        "hm_clear": (C.c_int, [vp]),
+        "hm_upload": (C.c_int, [vp]),
+        "hm_run": (C.c_int, [vp]),
+        "hm_sync": (C.c_int, [vp]),
+        "hm_num_sites": (i64, [vp, C.c_int]),
+        "hm_fetch": (i64, [vp, vp, i64]),
+        "hm_flush": (C.c_int, [vp]),
+        "hm_drain": (i64, [vp, vp, i64]),
+        "hm_scan_sites": (i64, [vp, C.c_int, vp, vp, vp, i64]),
+        "hm_windows": (C.c_int, [vp, C.c_int, i64, i64, vp]),
+        "hm_cnn_logits": (C.c_int, [vp, C.c_int, vp, i64, vp, vp, vp]),
+        "hm_debug_layer": (i64, [vp, C.c_int, vp, C.c_int, vp, i64]),
+        "hm_get_timing": (C.c_int, [vp, C.POINTER(hm_timing_t)]),
+        "hm_reset_timing": (C.c_int, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    L._hm_symbols = tuple(sig)
+    _lib = L
+    return L

@@ -1,0 +1,182 @@
+"""Host-side mirror of the reference's hot-path classes on top of the C ABI.
+
+The reference drives the path through three C++ classes inside its worker thread
+(src/app/hifimeth/mod_main.cpp:145-262): `ModModels` (model load), `EvalKmerFeaturesGenerator`
+(init / extract_*_samples / get_next_sample_features, eval_kmer_features.hpp:13-49) and `ModBatch`
+(call_mods_for_one_read / call_current_batch, mod_batch.hpp:12-43).  `MethylationCaller` offers the
+same verbs, batched: reads are staged, then one device pass scans all sites, builds their windows
+on chip and runs the CNN.  Everything below is plumbing around libhifimeth_hip.so; there is no CPU
+implementation here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Optional
+
+import numpy as np
+
+from . import _lib
+
+CPG, CHG, CHH = 0, 1, 2
+CTX_NAMES = ("CpG", "CHG", "CHH")
+KMER, FEATS = 401, 8
+
+CALL_DTYPE = np.dtype([("read_id", "<i4"), ("qoff", "<i4"), ("strand", "u1"), ("ctx", "u1"),
+                       ("scaled_prob", "u1"), ("reserved", "u1"), ("p", "<f4")])
+assert CALL_DTYPE.itemsize == C.sizeof(_lib.hm_call_t) == 16
+
+
+class HifimethError(RuntimeError):
+    pass
+
+
+def parse_contexts(spec: str) -> int:
+    """The reference's `-c cpg,chg,chh` (mod_options.cpp:61-134) -> ctx_mask."""
+    mask = 0
+    for tok in spec.lower().split(","):
+        tok = tok.strip()
+        if tok not in ("cpg", "chg", "chh"):
+            raise ValueError(f"unknown methylation context '{tok}'")
+        mask |= 1 << ("cpg", "chg", "chh").index(tok)
+    return mask
+
+
+def _vp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class MethylationCaller:
+    def __init__(self, model_dir: Optional[str] = None, contexts: str = "cpg,chg,chh", device: int = 0,
+                 min_read_size: int = 1000, timing: bool = False):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        self.ctx_mask = parse_contexts(contexts)
+        rc = self._L.hm_create(C.byref(self._h), (model_dir or _lib.WEIGHTS_DIR).encode(), self.ctx_mask, device)
+        if rc < 0:
+            self._h = None
+            raise HifimethError(f"hm_create failed ({rc}): {self._L.hm_last_error(None).decode()}")
+        self.set_option("min_read_size", min_read_size)
+        self.set_option("timing", int(timing))
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.hm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise HifimethError(f"{what} failed ({rc}): {self._L.hm_last_error(self._h).decode()}")
+        return rc
+
+    def set_option(self, key: str, value: int):
+        self._check(self._L.hm_set_option(self._h, key.encode(), int(value)), f"hm_set_option({key})")
+
+    # -- staging (EvalKmerFeaturesGenerator::init) ------------------------------------------------
+    def submit(self, read_id: int, read) -> bool:
+        """`read`: object with l_qseq, flag, seq4 and fi/fp/ri/rp (uint8 or uint16 arrays, or None).
+        True if accepted, False if passed through uncalled (short read / missing kinetics)."""
+        arrs, widths = [], []
+        for nm in ("fi", "fp", "ri", "rp"):
+            a = getattr(read, nm)
+            if a is not None:
+                if len(a) != read.l_qseq:  # bam_auxB_len != l_qseq -> init() == false (bam_info.cpp:447)
+                    a = None
+                else:
+                    a = np.ascontiguousarray(a)
+                    if a.dtype.itemsize not in (1, 2):
+                        raise ValueError("kinetics arrays must be uint8 (B:C) or uint16 (B:S)")
+            arrs.append(a)
+            widths.append(1 if a is None else a.dtype.itemsize)
+        seq4 = np.ascontiguousarray(read.seq4, np.uint8)
+        rc = self._L.hm_submit_read(self._h, read_id, read.l_qseq, read.flag, _vp(seq4),
+                                    _vp(arrs[0]), widths[0], _vp(arrs[1]), widths[1],
+                                    _vp(arrs[2]), widths[2], _vp(arrs[3]), widths[3])
+        return bool(self._check(rc, "hm_submit_read"))
+
+    def submit_all(self, reads: Iterable, first_id: int = 0) -> int:
+        n = 0
+        for i, r in enumerate(reads):
+            n += self.submit(first_id + i, r)
+        return n
+
+    def clear(self):
+        self._check(self._L.hm_clear(self._h), "hm_clear")
+
+    # -- execution -------------------------------------------------------------------------------
+    def upload(self):
+        self._check(self._L.hm_upload(self._h), "hm_upload")
+
+    def run(self):
+        self._check(self._L.hm_run(self._h), "hm_run")
+
+    def sync(self):
+        self._check(self._L.hm_sync(self._h), "hm_sync")
+
+    def num_sites(self, ctx: int = 3) -> int:
+        return self._check(self._L.hm_num_sites(self._h, ctx), "hm_num_sites")
+
+    def fetch(self) -> np.ndarray:
+        self.sync()
+        n = self.num_sites(3)
+        out = np.empty(n, CALL_DTYPE)
+        got = self._check(self._L.hm_fetch(self._h, _vp(out), n), "hm_fetch")
+        return out[:got]
+
+    def call(self, reads: Iterable, first_id: int = 0) -> np.ndarray:
+        """Stage, run and fetch in one go; returns CALL_DTYPE records ordered by (read, strand, qoff)."""
+        self.clear()
+        self.submit_all(reads, first_id)
+        self.upload()
+        self.run()
+        out = self.fetch()
+        self.clear()
+        return out
+
+    # -- seams -------------------------------------------------------------------------------------
+    def scan_sites(self, ctx: int):
+        """extract_{cpg,chg,chh}_samples of every staged read: (read_id, qoff, strand) in (read, qoff) order."""
+        self.sync()
+        n = self.num_sites(ctx)
+        rid, qoff, strand = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.uint8)
+        self._check(self._L.hm_scan_sites(self._h, ctx, _vp(rid), _vp(qoff), _vp(strand), n), "hm_scan_sites")
+        return rid, qoff, strand
+
+    def windows(self, ctx: int, first: int = 0, n: Optional[int] = None, fetch: bool = True):
+        """get_next_sample_features for sites [first, first+n) of context ctx -> float32 [n, 401, 8]."""
+        if n is None:
+            n = self.num_sites(ctx) - first
+        out = np.empty((n, KMER, FEATS), np.float32) if fetch else None
+        self._check(self._L.hm_windows(self._h, ctx, first, n, _vp(out)), "hm_windows")
+        return out
+
+    def cnn_logits(self, ctx: int, windows: np.ndarray):
+        """ModBatch::call_current_batch on a [n, 401, 8] batch -> (logits [n,2], p [n], ml [n])."""
+        w = np.ascontiguousarray(windows, np.float32).reshape(-1, KMER, FEATS)
+        n = w.shape[0]
+        lg, p, ml = np.empty((n, 2), np.float32), np.empty(n, np.float32), np.empty(n, np.uint8)
+        self._check(self._L.hm_cnn_logits(self._h, ctx, _vp(w), n, _vp(lg), _vp(p), _vp(ml)), "hm_cnn_logits")
+        return lg, p, ml
+
+    def debug_layer(self, ctx: int, window: np.ndarray, layer: int) -> np.ndarray:
+        w = np.ascontiguousarray(window, np.float32).reshape(KMER, FEATS)
+        out = np.empty(197 * 128, np.float32)
+        n = self._check(self._L.hm_debug_layer(self._h, ctx, _vp(w), layer, _vp(out), out.size), "hm_debug_layer")
+        chans = (8, 128, 128, 128, 96, 96, 96, 64, 64)[layer]
+        return out[:n].reshape(-1, chans).copy()
+
+    def timing(self, reset: bool = False) -> dict:
+        t = _lib.hm_timing_t()
+        self._check(self._L.hm_get_timing(self._h, C.byref(t)), "hm_get_timing")
+        d = {k: (list(getattr(t, k)) if hasattr(getattr(t, k), "__len__") else getattr(t, k)) for k, _ in t._fields_}
+        if reset:
+            self._L.hm_reset_timing(self._h)
+        return d

@@ -1,0 +1,67 @@
+// hm_device.h -- structures shared by the host engine and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+namespace hm {
+
+constexpr int KMER = 401;     // models/kmer.txt
+constexpr int FEATS = 8;      // eval_kmer_features.cpp:42-64
+constexpr int HK = 200;
+constexpr int CHUNK = 1024;   // bases per prep/scan workgroup
+constexpr int NCTX = 3;
+
+enum { CPG = 0, CHG = 1, CHH = 2, CTX_NONE = 3 };
+
+// One read of a staged batch.  Offsets are byte offsets into the raw slab exactly as the BAM
+// record stores the arrays (4-bit seq; fi/fp/ri/rp as B:C bytes or B:S u16).
+struct ReadDesc {
+    int64_t off_seq, off_fi, off_fp, off_ri, off_rp;
+    int64_t base_off;   // first element of this read in the packed per-base arrays
+    int32_t len;
+    int32_t flag;
+    int32_t read_id;
+    uint8_t w[4];       // element width of fi, fp, ri, rp (1 or 2)
+};
+
+struct Chunk {
+    int32_t read_idx;
+    int32_t start;      // first forward-strand position of the chunk
+};
+
+// site of one context list; uidx = rank in the unified (read, qoff)-ordered list
+struct Site {
+    int32_t read_idx;
+    int32_t qoff;
+    int32_t uidx;
+};
+
+struct USite {
+    int32_t read_idx;
+    int32_t qoff;
+};
+
+// bn0 folded into lookup tables, computed on the host with the ONNX BatchNormalization
+// formula so that device windows equal the oracle's bn0 output bit for bit.
+struct BnTables {
+    float hot[4];        // bn0(1.0) for the one-hot channels 0..3
+    float zero[8];       // bn0(0.0) for all 8 channels (cold one-hot; rows outside the read)
+    float mean[8], gamma[8], beta[8], sd[8];   // sd = sqrtf(var + eps)  (windows-from-memory mode)
+    float lut[4][256];   // bn0(codev1_decode(code) / 952) for channels 4..7
+    float raw_lut[256];  // codev1_decode(code) / 952 (fp32 divide, eval_kmer_features.cpp:46-60)
+};
+
+// per-context device weights: MFMA-fragment-packed conv/fc weights + biases
+struct CtxWeights {
+    const float* wfrag[9];   // conv1..conv8, fc1 : [n-tile][k-group][lane][4]
+    const float* bias[9];
+    const float* fc2_w;      // [2][256]
+    const float* fc2_b;      // [2]
+    const BnTables* bn;
+    int k1;
+};
+
+constexpr int C4_LEN = 25, C4_CH = 96;          // conv4 output = hand-off between front and tail kernels
+constexpr int ACT4_FLOATS = C4_LEN * C4_CH;      // 2400 floats / site
+constexpr int TAIL_SITES = 8;                    // sites stacked along M in the tail kernel
+
+}  // namespace hm

@@ -1,0 +1,38 @@
+// hm_kernels.h -- host-callable launchers of the gfx950 kernels (defined in hm_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hm_device.h"
+
+namespace hm {
+
+// feature extraction -------------------------------------------------------------------------
+// A: decode 4-bit bases to forward-strand codes, pack the four kinetics arrays per forward
+//    position, count sites per 1024-base chunk.
+void launch_prep(hipStream_t st, const uint8_t* raw, const ReadDesc* reads, const Chunk* chunks, int n_chunks,
+                 int ctx_mask, uint8_t* bases, uint32_t* kin, int32_t* chunk_counts, int32_t* err);
+// S: exclusive scan of the chunk counts -> chunk offsets, totals[4] (CpG, CHG, CHH, all), ctx_base[3].
+void launch_scan(hipStream_t st, const int32_t* chunk_counts, int n_chunks, int32_t* chunk_offs, int32_t* totals);
+// B: emit the unified (read, qoff)-ordered site list and the per-context lists.
+void launch_emit(hipStream_t st, const ReadDesc* reads, const Chunk* chunks, int n_chunks, int ctx_mask,
+                 const uint8_t* bases, const int32_t* chunk_offs, const int32_t* totals, USite* usites,
+                 uint8_t* utag, Site* csites);
+// W: materialise raw (no bn0) 401x8 fp32 windows for a site list: out[n][401][8].
+void launch_windows(hipStream_t st, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
+                    const uint32_t* kin, const BnTables* bn, float* out, int grid);
+
+// CNN ------------------------------------------------------------------------------------------
+// front: window (from staged reads, or from materialised windows when `windows` != nullptr)
+//        -> bn0 -> conv1..conv4 -> act4[n][25][96]
+void launch_front(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
+                  const uint32_t* kin, const float* windows, const CtxWeights& w, float* act4, int grid,
+                  float* dbg, int dbg_layer);
+// tail: conv5..conv8, fc1, fc2, softmax for 8 sites per workgroup pass.
+// results go to index sites[i].uidx (or i when sites == nullptr).
+void launch_tail(hipStream_t st, const float* act4, int n, const CtxWeights& w, const Site* sites, float* logits,
+                 float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer);
+
+size_t front_lds_bytes(int k1);
+size_t tail_lds_bytes();
+
+}  // namespace hm

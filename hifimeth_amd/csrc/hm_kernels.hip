@@ -1,0 +1,720 @@
+// hm_kernels.hip -- gfx950 (CDNA4) kernels of the 5mC calling hot path.
+//
+//   prep / scan / emit : site scanner + kinetics packer  (reference: src/app/hifimeth/
+//                        eval_kmer_features.cpp:67-126, src/corelib/bam_info.cpp:169-222,443-603)
+//   windows            : 401x8 window builder            (eval_kmer_features.cpp:9-65)
+//   front / tail       : the CNN of training/model_cnn.py:8-85 as shipped in models/*.onnx,
+//                        fp32 MFMA (v_mfma_f32_16x16x4_f32), activations tiled in LDS
+//                        (replaces ov::InferRequest::infer(), mod_batch.cpp:66-75) and
+//                        the softmax -> ML byte of mod_batch.cpp:46-64.
+//
+// Written for wave64 / gfx950 only.
+#include "hm_kernels.h"
+
+#include <type_traits>
+
+namespace hm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// =================================================================================================
+// feature extraction
+// =================================================================================================
+
+// BAM nibble -> code A0 C1 G2 T3, N (15) -> 4; anything else is illegal (bam_info.cpp:100-121 aborts)
+__device__ __forceinline__ int nib_to_code(int nib, int& bad) {
+    switch (nib) {
+    case 1: return 0;
+    case 2: return 1;
+    case 4: return 2;
+    case 8: return 3;
+    case 15: return 4;
+    default: bad = 1; return 4;
+    }
+}
+
+// forward-strand code of position j; positions outside the read give 4 (breaks every motif)
+__device__ __forceinline__ int fwd_code(const uint8_t* __restrict__ raw, const ReadDesc& rd, int j, int& bad) {
+    if (j < 0 || j >= rd.len) return 4;
+    const int rev = rd.flag & 16;  // stored sequence is the reverse strand (bam_info.cpp:180-192)
+    const int idx = rev ? rd.len - 1 - j : j;
+    const int byte = raw[rd.off_seq + (idx >> 1)];
+    const int nib = (idx & 1) ? (byte & 15) : (byte >> 4);
+    int c = nib_to_code(nib, bad);
+    if (rev && c < 4) c = 3 - c;
+    return c;
+}
+
+// s_encode_signal_value (bam_info.cpp:455-478): u16 frame count -> codev1 byte
+__device__ __forceinline__ int encode_frames(int s) {
+    s = s > 952 ? 952 : s;
+    if (s >= 448) return (s - 448) / 8 + 192;
+    if (s >= 192) return (s - 192) / 4 + 128;
+    if (s >= 64) return (s - 64) / 2 + 64;
+    return s;
+}
+
+__device__ __forceinline__ uint32_t kin_code(const uint8_t* __restrict__ raw, int64_t off, int w, int idx) {
+    if (w == 1) return raw[off + idx];
+    const uint32_t v = raw[off + 2 * (int64_t)idx] | ((uint32_t)raw[off + 2 * (int64_t)idx + 1] << 8);
+    return (uint32_t)encode_frames((int)v);
+}
+
+// context of the cytosine (forward C, or reverse-strand C seen as forward G) at the middle code.
+// CpG : C G                      forward only   (eval_kmer_features.cpp:89-102)
+// CHG : C [ACT] G                forward only   (:104-126)
+// CHH : C [ACT] [ACT] forward ; [AGT] [AGT] G -> site on the G, reverse strand (:67-87)
+__device__ __forceinline__ int classify(int cm2, int cm1, int c0, int c1, int c2) {
+    if (c0 == 1) {
+        if (c1 == 2) return CPG;
+        const bool h1 = (c1 == 0) | (c1 == 1) | (c1 == 3);
+        if (!h1) return CTX_NONE;
+        if (c2 == 2) return CHG;
+        if ((c2 == 0) | (c2 == 1) | (c2 == 3)) return CHH;
+        return CTX_NONE;
+    }
+    if (c0 == 2) {
+        const bool d1 = (cm1 == 0) | (cm1 == 2) | (cm1 == 3);
+        const bool d2 = (cm2 == 0) | (cm2 == 2) | (cm2 == 3);
+        return (d1 & d2) ? CHH : CTX_NONE;
+    }
+    return CTX_NONE;
+}
+
+constexpr int PREP_THREADS = 256;
+constexpr int PER_THREAD = CHUNK / PREP_THREADS;  // 4 consecutive positions per thread
+static_assert(PER_THREAD == 4, "prep kernels assume 4 positions per thread");
+
+__global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const uint8_t* __restrict__ raw,
+                                                              const ReadDesc* __restrict__ reads,
+                                                              const Chunk* __restrict__ chunks, int ctx_mask,
+                                                              uint8_t* __restrict__ bases,
+                                                              uint32_t* __restrict__ kin,
+                                                              int32_t* __restrict__ chunk_counts,
+                                                              int32_t* __restrict__ err) {
+    __shared__ int cnt[4];
+    const Chunk ch = chunks[blockIdx.x];
+    const ReadDesc rd = reads[ch.read_idx];
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int j0 = ch.start + PER_THREAD * threadIdx.x;
+    int bad = 0;
+    int c[PER_THREAD + 4];
+#pragma unroll
+    for (int t = 0; t < PER_THREAD + 4; ++t) c[t] = fwd_code(raw, rd, j0 - 2 + t, bad);
+    int my[3] = {0, 0, 0};
+    if (j0 < rd.len) {
+        uint32_t bpack = 0;
+        uint32_t kq[PER_THREAD];
+#pragma unroll
+        for (int t = 0; t < PER_THREAD; ++t) {
+            const int j = j0 + t;
+            kq[t] = 0;
+            if (j < rd.len) {
+                bpack |= (uint32_t)c[t + 2] << (8 * t);
+                // forward-coordinate packing: byte0 fi[j], byte1 fp[j], byte2 ri[L-1-j], byte3 rp[L-1-j]
+                // (kinetics are indexed exactly as stored in the tag: bam_info.cpp:520-548)
+                const int jr = rd.len - 1 - j;
+                kq[t] = kin_code(raw, rd.off_fi, rd.w[0], j) | (kin_code(raw, rd.off_fp, rd.w[1], j) << 8) |
+                        (kin_code(raw, rd.off_ri, rd.w[2], jr) << 16) | (kin_code(raw, rd.off_rp, rd.w[3], jr) << 24);
+                const int cls = classify(c[t], c[t + 1], c[t + 2], c[t + 3], c[t + 4]);
+                if (cls != CTX_NONE && ((ctx_mask >> cls) & 1)) ++my[cls];
+            }
+        }
+        const int64_t g = rd.base_off + j0;  // base_off and chunk starts are multiples of 4
+        if (j0 + PER_THREAD <= rd.len) {
+            *reinterpret_cast<uint32_t*>(bases + g) = bpack;
+            *reinterpret_cast<uint4*>(kin + g) = make_uint4(kq[0], kq[1], kq[2], kq[3]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < PER_THREAD; ++t)
+                if (j0 + t < rd.len) {
+                    bases[g + t] = (uint8_t)c[t + 2];
+                    kin[g + t] = kq[t];
+                }
+        }
+    }
+    if (my[0]) atomicAdd(&cnt[0], my[0]);
+    if (my[1]) atomicAdd(&cnt[1], my[1]);
+    if (my[2]) atomicAdd(&cnt[2], my[2]);
+    if (bad) atomicOr(err, 1);
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int v = threadIdx.x < 3 ? cnt[threadIdx.x] : cnt[0] + cnt[1] + cnt[2];
+        chunk_counts[4 * blockIdx.x + threadIdx.x] = v;
+    }
+}
+
+// single-workgroup exclusive scan of the 4 per-chunk counters
+constexpr int SCAN_THREADS = 1024;
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const int32_t* __restrict__ counts, int n_chunks,
+                                                             int32_t* __restrict__ offs,
+                                                             int32_t* __restrict__ totals) {
+    __shared__ int part[4][SCAN_THREADS];
+    const int per = (n_chunks + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int lo = threadIdx.x * per, hi = min(n_chunks, lo + per);
+    int s[4] = {0, 0, 0, 0};
+    for (int i = lo; i < hi; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] += counts[4 * i + c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) part[c][threadIdx.x] = s[c];
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 1024 partials
+    for (int d = 1; d < SCAN_THREADS; d <<= 1) {
+        int v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = threadIdx.x >= d ? part[c][threadIdx.x - d] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) part[c][threadIdx.x] += v[c];
+        __syncthreads();
+    }
+    int run[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) run[c] = part[c][threadIdx.x] - s[c];  // exclusive prefix of this thread's range
+    for (int i = lo; i < hi; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            offs[4 * i + c] = run[c];
+            run[c] += counts[4 * i + c];
+        }
+    if (threadIdx.x == SCAN_THREADS - 1) {
+        const int t0 = part[0][threadIdx.x], t1 = part[1][threadIdx.x], t2 = part[2][threadIdx.x];
+        totals[0] = t0;
+        totals[1] = t1;
+        totals[2] = t2;
+        totals[3] = part[3][threadIdx.x];
+        totals[4] = 0;        // ctx_base: the three context lists are laid out back to back
+        totals[5] = t0;
+        totals[6] = t0 + t1;
+    }
+}
+
+// wave64 inclusive prefix sum
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(PREP_THREADS) void emit_kernel(const ReadDesc* __restrict__ reads,
+                                                              const Chunk* __restrict__ chunks, int ctx_mask,
+                                                              const uint8_t* __restrict__ bases,
+                                                              const int32_t* __restrict__ chunk_offs,
+                                                              const int32_t* __restrict__ totals,
+                                                              USite* __restrict__ usites, uint8_t* __restrict__ utag,
+                                                              Site* __restrict__ csites) {
+    __shared__ int wave_tot[3][PREP_THREADS / 64];
+    const Chunk ch = chunks[blockIdx.x];
+    const ReadDesc rd = reads[ch.read_idx];
+    const int j0 = ch.start + PER_THREAD * threadIdx.x;
+    int c[PER_THREAD + 4];
+#pragma unroll
+    for (int t = 0; t < PER_THREAD + 4; ++t) {
+        const int j = j0 - 2 + t;
+        c[t] = (j >= 0 && j < rd.len) ? bases[rd.base_off + j] : 4;
+    }
+    int cls[PER_THREAD];
+    int my[3] = {0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < PER_THREAD; ++t) {
+        int k = CTX_NONE;
+        if (j0 + t < rd.len) {
+            k = classify(c[t], c[t + 1], c[t + 2], c[t + 3], c[t + 4]);
+            if (k != CTX_NONE && !((ctx_mask >> k) & 1)) k = CTX_NONE;
+        }
+        cls[t] = k;
+        if (k != CTX_NONE) ++my[k];
+    }
+    // wavefront-level scans, then a 4-wave carry through LDS
+    int incl[3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        incl[k] = wave_incl_scan(my[k]);
+        if (lane == 63) wave_tot[k][wave] = incl[k];
+    }
+    __syncthreads();
+    int rank[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int carry = 0;
+        for (int w = 0; w < wave; ++w) carry += wave_tot[k][w];
+        rank[k] = chunk_offs[4 * blockIdx.x + k] + carry + incl[k] - my[k];
+    }
+    // rank in the unified list: sites of all contexts in position order. chunk_offs[..][3] was
+    // scanned from the per-chunk sum, thread-local order is position order, so the unified rank is
+    // the chunk's unified offset plus the number of sites (any context) before this one in the chunk.
+    const int ubase = chunk_offs[4 * blockIdx.x + 3];
+    int urank = ubase + (rank[0] - chunk_offs[4 * blockIdx.x + 0]) + (rank[1] - chunk_offs[4 * blockIdx.x + 1]) +
+                (rank[2] - chunk_offs[4 * blockIdx.x + 2]);
+#pragma unroll
+    for (int t = 0; t < PER_THREAD; ++t) {
+        const int k = cls[t];
+        if (k == CTX_NONE) continue;
+        const int q = j0 + t;
+        const int strand = c[t + 2] == 2 ? 1 : 0;  // forward G = cytosine on the reverse strand
+        usites[urank] = USite{ch.read_idx, q};
+        utag[urank] = (uint8_t)(k | (strand << 2));
+        csites[totals[4 + k] + rank[k]] = Site{ch.read_idx, q, urank};
+        ++rank[k];
+        ++urank;
+    }
+}
+
+// one 401x8 window per workgroup pass, written as 802 coalesced float4 (12 832 B / site)
+__global__ __launch_bounds__(256) void window_kernel(const Site* __restrict__ sites, int n,
+                                                      const ReadDesc* __restrict__ reads,
+                                                      const uint8_t* __restrict__ bases,
+                                                      const uint32_t* __restrict__ kin,
+                                                      const BnTables* __restrict__ bn, float* __restrict__ out) {
+    for (int s = blockIdx.x; s < n; s += gridDim.x) {
+        const Site st = sites[s];
+        const int L = reads[st.read_idx].len;
+        const int64_t bo = reads[st.read_idx].base_off;
+        const int rev = bases[bo + st.qoff] == 2;
+        float4* dst = reinterpret_cast<float4*>(out + (size_t)s * (KMER * FEATS));
+        for (int q = threadIdx.x; q < KMER * 2; q += 256) {
+            const int r = q >> 1;
+            const int j = rev ? st.qoff + HK - r : st.qoff - HK + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j >= 0 && j < L) {
+                if (!(q & 1)) {
+                    int b = bases[bo + j];
+                    if (rev && b < 4) b = 3 - b;
+                    v = make_float4(b == 0 ? 1.f : 0.f, b == 1 ? 1.f : 0.f, b == 2 ? 1.f : 0.f, b == 3 ? 1.f : 0.f);
+                } else {
+                    uint32_t k = kin[bo + j];
+                    if (rev) k = (k >> 16) | (k << 16);  // own strand first: (ri, rp, fi, fp)
+                    v = make_float4(bn->raw_lut[k & 255], bn->raw_lut[(k >> 8) & 255], bn->raw_lut[(k >> 16) & 255],
+                                    bn->raw_lut[k >> 24]);
+                }
+            }
+            dst[q] = v;
+        }
+    }
+}
+
+// =================================================================================================
+// CNN: implicit-GEMM conv1d(stride 2, pad 1) on v_mfma_f32_16x16x4_f32
+// =================================================================================================
+//
+// One layer = GEMM  Out[m][co] = sum_kk A[m][kk] * Wk[kk][co],  m = (site, p) stacked over S sites,
+// kk = tap*CIN + c,  A[m][kk] = in[site][2p - 1 + tap][c].  Activations live in LDS channels-last
+// with one zero row in front of and behind every site (the conv's own padding), so the im2col row
+// of output position p is the contiguous slice starting at physical row 2p:
+//     A[m][kk] = lds[site*ISS + (2p + ROW0 + tap)*IRS + c]
+// Row strides are == 1 (mod 16) floats, which makes the 16-row x 2-k ds_read_b32 pattern of the
+// A fragment (lane l: row l&15, k = l>>4) bank-conflict free.
+// Weights are pre-packed on the host in fragment order [n-tile][k-group of 16][lane][4]: lane l of
+// n-tile nt holds Wk[kg*16 + 4*s + (l>>4)][nt*16 + (l&15)] in component s, so every lane fetches the
+// B operands of four consecutive k-steps with one 16-byte load straight from L2.
+// The 4 waves of a workgroup tile the output as WM x WN blocks of (MTW x NTW) 16x16 tiles.
+
+template <int S_, int CIN_, int KT_, int COUT_, int LOUT_, int IRS_, int ISS_, int ROW0_, int WM_, int WN_>
+struct Conv {
+    static constexpr int S = S_, CIN = CIN_, KT = KT_, COUT = COUT_, LOUT = LOUT_, IRS = IRS_, ISS = ISS_;
+    static constexpr int ROW0 = ROW0_, WM = WM_, WN = WN_;
+    static constexpr int M = S * LOUT;
+    static constexpr int MT = (M + 15) / 16;
+    static constexpr int NT = COUT / 16;
+    static constexpr int MTW = (MT + WM - 1) / WM;
+    static constexpr int NTW = NT / WN;
+    static constexpr int K = KT * CIN;
+    static constexpr int KG = K / 16;
+    static_assert(K % 16 == 0 && COUT % 16 == 0 && NT % WN == 0 && WM * WN == 4 && CIN % 4 == 0, "bad conv geometry");
+
+    template <class Epi>
+    static __device__ __forceinline__ void run(const float* __restrict__ in, const float* __restrict__ wfrag, Epi epi) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        const int li = lane & 15, lk = lane >> 4;
+
+        int aoff[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            int m = (wm * MTW + i) * 16 + li;
+            m = m < M ? m : M - 1;  // rows of the ragged last tile re-read the last valid row (discarded later)
+            const int site = m / LOUT, p = m - site * LOUT;
+            aoff[i] = site * ISS + (2 * p + ROW0) * IRS + lk;
+        }
+        f32x4 acc[MTW][NTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        const float4* wp = reinterpret_cast<const float4*>(wfrag) + (size_t)(wn * NTW) * KG * 64 + lane;
+        float4 bq[2][NTW];
+        float a[2][MTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bq[0][j] = wp[(size_t)(j * KG) * 64];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) a[0][i] = in[aoff[i]];  // k-step 0: tap 0, channel 0
+
+        auto group = [&](auto cb_tag, const int kg) __attribute__((always_inline)) {
+            constexpr int CB = decltype(cb_tag)::value;
+            if (kg + 1 < KG) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) bq[CB ^ 1][j] = wp[(size_t)(j * KG + kg + 1) * 64];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ks = kg * 4 + s;
+                if (ks + 1 < KG * 4) {  // fetch the A fragments of the next k-step while this one multiplies
+                    const int kk = (ks + 1) * 4;
+                    const int tap = kk / CIN;
+                    const int ko = tap * IRS + (kk - tap * CIN);
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i) a[(s + 1) & 1][i] = in[aoff[i] + ko];
+                }
+#pragma unroll
+                for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        const float bv = s == 0 ? bq[CB][j].x : s == 1 ? bq[CB][j].y : s == 2 ? bq[CB][j].z : bq[CB][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][i], bv, acc[i][j], 0, 0, 0);
+                    }
+            }
+        };
+        int kg = 0;
+#pragma nounroll
+        for (; kg + 1 < KG; kg += 2) {
+            group(std::integral_constant<int, 0>{}, kg);
+            group(std::integral_constant<int, 1>{}, kg + 1);
+        }
+        if (KG & 1) group(std::integral_constant<int, 0>{}, KG - 1);
+
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) epi(wm * MTW + i, wn * NTW + j, acc[i][j]);
+    }
+};
+
+// bias + ReLU, result to LDS channels-last with row stride ORS / site stride OSS (physical row p+1).
+template <int LOUT, int M, int ORS, int OSS>
+struct EpiLds {
+    float* out;
+    const float* __restrict__ bias;
+    __device__ __forceinline__ void operator()(int mt, int nt, const f32x4& acc) const {
+        const int lane = threadIdx.x & 63;
+        const int col = nt * 16 + (lane & 15);
+        const float bv = bias[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mt * 16 + (lane >> 4) * 4 + r;  // C/D layout: row = (lane>>4)*4 + reg, col = lane&15
+            if (m < M) {
+                const int site = m / LOUT, p = m - site * LOUT;
+                out[site * OSS + (p + 1) * ORS + col] = fmaxf(acc[r] + bv, 0.f);
+            }
+        }
+    }
+};
+
+// bias + ReLU, result to global channels-last [m][COUT]
+template <int M, int COUT>
+struct EpiGlobal {
+    float* __restrict__ out;
+    const float* __restrict__ bias;
+    int m_valid;
+    __device__ __forceinline__ void operator()(int mt, int nt, const f32x4& acc) const {
+        const int lane = threadIdx.x & 63;
+        const int col = nt * 16 + (lane & 15);
+        const float bv = bias[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mt * 16 + (lane >> 4) * 4 + r;
+            if (m < M && m < m_valid) out[(size_t)m * COUT + col] = fmaxf(acc[r] + bv, 0.f);
+        }
+    }
+};
+
+// zero the padding rows (physical rows 0 and LOUT+1) of S stacked sites
+template <int S, int LOUT, int COUT, int ORS, int OSS>
+__device__ __forceinline__ void zero_pad_rows(float* out) {
+    for (int i = threadIdx.x; i < S * 2 * COUT; i += 256) {
+        const int site = i / (2 * COUT), rem = i - site * 2 * COUT;
+        const int which = rem / COUT, c = rem - which * COUT;
+        out[site * OSS + (which ? (LOUT + 1) : 0) * ORS + c] = 0.f;
+    }
+}
+
+template <int L, int C, int RS>
+__device__ __forceinline__ void dump_lds(const float* buf, float* __restrict__ dbg) {
+    for (int i = threadIdx.x; i < L * C; i += 256) dbg[i] = buf[(i / C + 1) * RS + (i % C)];
+}
+
+// ------------------------------------------------------------------------------------------------
+// front kernel: window -> bn0 -> conv1 .. conv4   (one site per workgroup pass, all in LDS)
+// ------------------------------------------------------------------------------------------------
+template <int K1>
+struct Geo {
+    static constexpr int L1 = (KMER + 2 - K1) / 2 + 1;  // 197 (k=11) / 196 (k=13)
+    static constexpr int L2 = (L1 - 1) / 2 + 1;         // 99 / 98
+    static constexpr int L3 = (L2 - 1) / 2 + 1;         // 50 / 49
+    static constexpr int L4 = (L3 - 1) / 2 + 1;         // 25 / 25
+    static_assert(L4 == C4_LEN, "conv4 length");
+    static constexpr int KT1 = (K1 * FEATS + 15) / 16 * 2;  // taps incl. zero-weight K padding: 12 / 14
+    static constexpr int WRS = 9;                            // window row stride (floats)
+    static constexpr int WROWS = 2 * (L1 - 1) + KT1;         // physical window rows touched by conv1
+    static constexpr int RS = 129;                           // row stride of the 128-channel activations
+    static constexpr int A1 = (L1 + 2) * RS, A2 = (L2 + 2) * RS, A3 = (L3 + 2) * RS, WIN = WROWS * WRS;
+    static constexpr int BUFA = A1 > A3 ? A1 : A3;
+    static constexpr int BUFB = WIN > A2 ? WIN : A2;
+    static constexpr int LDS_FLOATS = BUFA + BUFB;
+};
+
+template <int K1, bool RAW>
+__global__ __launch_bounds__(256) void front_kernel(const Site* __restrict__ sites, int n_sites,
+                                                     const ReadDesc* __restrict__ reads,
+                                                     const uint8_t* __restrict__ bases,
+                                                     const uint32_t* __restrict__ kin,
+                                                     const float* __restrict__ windows, CtxWeights W,
+                                                     float* __restrict__ act4, float* __restrict__ dbg, int dbg_layer) {
+    using G = Geo<K1>;
+    __shared__ float smem[G::LDS_FLOATS];
+    float* bufA = smem;
+    float* bufB = smem + G::BUFA;
+    const BnTables* __restrict__ bn = W.bn;
+
+    for (int s = blockIdx.x; s < n_sites; s += gridDim.x) {
+        // ---- window rows -> bufB, bn0 applied.  physical row pr holds window row pr-1; rows
+        // outside [0,401) are the conv's zero padding (and the zero-weight K padding of conv1).
+        if (RAW) {
+            const Site st = sites[s];
+            const int L = reads[st.read_idx].len;
+            const int64_t bo = reads[st.read_idx].base_off;
+            const int rev = bases[bo + st.qoff] == 2;
+            for (int pr = threadIdx.x; pr < G::WROWS; pr += 256) {
+                const int w = pr - 1;
+                float v[8];
+                if (w < 0 || w >= KMER) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = 0.f;
+                } else {
+                    const int j = rev ? st.qoff + HK - w : st.qoff - HK + w;
+                    if (j < 0 || j >= L) {  // outside the read: the reference zero-fills BEFORE bn0
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] = bn->zero[c];
+                    } else {
+                        int b = bases[bo + j];
+                        uint32_t k = kin[bo + j];
+                        if (rev) {
+                            if (b < 4) b = 3 - b;
+                            k = (k >> 16) | (k << 16);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = b == c ? bn->hot[c] : bn->zero[c];
+                        v[4] = bn->lut[0][k & 255];
+                        v[5] = bn->lut[1][(k >> 8) & 255];
+                        v[6] = bn->lut[2][(k >> 16) & 255];
+                        v[7] = bn->lut[3][k >> 24];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) bufB[pr * G::WRS + c] = v[c];
+            }
+        } else {
+            const float* __restrict__ src = windows + (size_t)s * (KMER * FEATS);
+            for (int i = threadIdx.x; i < G::WROWS * 8; i += 256) {
+                const int pr = i >> 3, c = i & 7, w = pr - 1;
+                float v = 0.f;
+                if (w >= 0 && w < KMER) v = (src[w * 8 + c] - bn->mean[c]) / bn->sd[c] * bn->gamma[c] + bn->beta[c];
+                bufB[pr * G::WRS + c] = v;
+            }
+        }
+        __syncthreads();
+
+        // conv1: window (bufB) -> bufA
+        Conv<1, 8, G::KT1, 128, G::L1, G::WRS, 0, 0, 1, 4>::run(
+            bufB, W.wfrag[0], EpiLds<G::L1, G::L1, G::RS, 0>{bufA, W.bias[0]});
+        zero_pad_rows<1, G::L1, 128, G::RS, 0>(bufA);
+        __syncthreads();
+        if (dbg && dbg_layer == 1 && s == 0) dump_lds<G::L1, 128, G::RS>(bufA, dbg);
+
+        // conv2: bufA -> bufB
+        Conv<1, 128, 3, 128, G::L2, G::RS, 0, 0, 1, 4>::run(
+            bufA, W.wfrag[1], EpiLds<G::L2, G::L2, G::RS, 0>{bufB, W.bias[1]});
+        zero_pad_rows<1, G::L2, 128, G::RS, 0>(bufB);
+        __syncthreads();
+        if (dbg && dbg_layer == 2 && s == 0) dump_lds<G::L2, 128, G::RS>(bufB, dbg);
+
+        // conv3: bufB -> bufA
+        Conv<1, 128, 3, 128, G::L3, G::RS, 0, 0, 1, 4>::run(
+            bufB, W.wfrag[2], EpiLds<G::L3, G::L3, G::RS, 0>{bufA, W.bias[2]});
+        zero_pad_rows<1, G::L3, 128, G::RS, 0>(bufA);
+        __syncthreads();
+        if (dbg && dbg_layer == 3 && s == 0) dump_lds<G::L3, 128, G::RS>(bufA, dbg);
+
+        // conv4: bufA -> act4[s] in HBM (hand-off to the tail kernel)
+        Conv<1, 128, 3, C4_CH, G::L4, G::RS, 0, 0, 2, 2>::run(
+            bufA, W.wfrag[3], EpiGlobal<G::L4, C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3], G::L4});
+        __syncthreads();  // bufA/bufB are rewritten by the next site
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tail kernel: conv5 .. conv8, fc1, fc2, softmax, 8 sites stacked along M per workgroup pass
+// ------------------------------------------------------------------------------------------------
+struct TailGeo {
+    static constexpr int S = TAIL_SITES;
+    static constexpr int L4 = 25, L5 = 13, L6 = 7, L7 = 4, L8 = 2;
+    static constexpr int RS96 = 97, RS64 = 65, HRS = 257;
+    static constexpr int IN_SS = (L4 + 2) * RS96, C5_SS = (L5 + 2) * RS96, C6_SS = (L6 + 2) * RS96;
+    static constexpr int C7_SS = (L7 + 2) * RS64, C8_SS = (L8 + 2) * RS64;
+    static constexpr int BUF0 = S * IN_SS;  // also holds conv6 / conv8 outputs
+    static constexpr int BUF1 = S * C5_SS;  // also holds conv7 output and the fc1 activations
+    static_assert(S * C6_SS <= BUF0 && S * C8_SS <= BUF0 && S * C7_SS <= BUF1 && S * HRS <= BUF1, "tail LDS plan");
+    static constexpr int LDS_FLOATS = BUF0 + BUF1;
+};
+
+__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ act4, int n_sites, CtxWeights W,
+                                                    const Site* __restrict__ sites, float* __restrict__ logits,
+                                                    float* __restrict__ prob, uint8_t* __restrict__ ml,
+                                                    float* __restrict__ dbg, int dbg_layer) {
+    using T = TailGeo;
+    constexpr int S = T::S;
+    __shared__ float smem[T::LDS_FLOATS];
+    float* buf0 = smem;
+    float* buf1 = smem + T::BUF0;
+
+    for (int g = blockIdx.x; g * S < n_sites; g += gridDim.x) {
+        const int s0 = g * S;
+        const int nv = min(S, n_sites - s0);
+        // act4 [site][25][96] -> buf0 rows 1..25 ; rows 0 and 26 are the conv padding
+        for (int i = threadIdx.x; i < S * (ACT4_FLOATS / 4); i += 256) {
+            const int site = i / (ACT4_FLOATS / 4), rem = (i - site * (ACT4_FLOATS / 4)) * 4;
+            const int pos = rem / C4_CH, c = rem - pos * C4_CH;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (site < nv) v = *reinterpret_cast<const float4*>(act4 + (size_t)(s0 + site) * ACT4_FLOATS + rem);
+            float* d = buf0 + site * T::IN_SS + (pos + 1) * T::RS96 + c;
+            d[0] = v.x;
+            d[1] = v.y;
+            d[2] = v.z;
+            d[3] = v.w;
+        }
+        zero_pad_rows<S, T::L4, 96, T::RS96, T::IN_SS>(buf0);
+        __syncthreads();
+
+        Conv<S, 96, 3, 96, T::L5, T::RS96, T::IN_SS, 0, 2, 2>::run(
+            buf0, W.wfrag[4], EpiLds<T::L5, S * T::L5, T::RS96, T::C5_SS>{buf1, W.bias[4]});
+        zero_pad_rows<S, T::L5, 96, T::RS96, T::C5_SS>(buf1);
+        __syncthreads();
+        if (dbg && dbg_layer == 5 && g == 0) dump_lds<T::L5, 96, T::RS96>(buf1, dbg);
+
+        Conv<S, 96, 3, 96, T::L6, T::RS96, T::C5_SS, 0, 2, 2>::run(
+            buf1, W.wfrag[5], EpiLds<T::L6, S * T::L6, T::RS96, T::C6_SS>{buf0, W.bias[5]});
+        zero_pad_rows<S, T::L6, 96, T::RS96, T::C6_SS>(buf0);
+        __syncthreads();
+        if (dbg && dbg_layer == 6 && g == 0) dump_lds<T::L6, 96, T::RS96>(buf0, dbg);
+
+        Conv<S, 96, 3, 64, T::L7, T::RS96, T::C6_SS, 0, 2, 2>::run(
+            buf0, W.wfrag[6], EpiLds<T::L7, S * T::L7, T::RS64, T::C7_SS>{buf1, W.bias[6]});
+        zero_pad_rows<S, T::L7, 64, T::RS64, T::C7_SS>(buf1);
+        __syncthreads();
+        if (dbg && dbg_layer == 7 && g == 0) dump_lds<T::L7, 64, T::RS64>(buf1, dbg);
+
+        Conv<S, 64, 3, 64, T::L8, T::RS64, T::C7_SS, 0, 1, 4>::run(
+            buf1, W.wfrag[7], EpiLds<T::L8, S * T::L8, T::RS64, T::C8_SS>{buf0, W.bias[7]});
+        __syncthreads();
+        if (dbg && dbg_layer == 8 && g == 0) dump_lds<T::L8, 64, T::RS64>(buf0, dbg);
+
+        // fc1 as a 2-tap "conv" over the two positions of conv8's output: A[site][l*64 + c] = rows 1,2.
+        // (weights are packed in that k order from fc1.weight[o][c*2 + l], the channel-major flatten
+        //  of model_cnn.py:79).  Output h[site][256] with row stride HRS: (p+1)*ORS with ORS = 0.
+        Conv<S, 64, 2, 256, 1, T::RS64, T::C8_SS, 1, 1, 4>::run(
+            buf0, W.wfrag[8], EpiLds<1, S, 0, T::HRS>{buf1, W.bias[8]});
+        __syncthreads();
+
+        // fc2 + softmax (mod_batch.cpp:46-64): 16 lanes per site = 2 outputs x 8 partial sums
+        if (threadIdx.x < S * 16) {
+            const int site = threadIdx.x >> 4, o = (threadIdx.x >> 3) & 1, part = threadIdx.x & 7;
+            const float* h = buf1 + site * T::HRS + part * 32;
+            const float* w2 = W.fc2_w + o * 256 + part * 32;
+            float sum = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) sum = fmaf(h[k], w2[k], sum);
+            sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 1, 64);
+            sum += W.fc2_b[o];
+            const float other = __shfl_xor(sum, 8, 64);
+            if ((threadIdx.x & 15) == 0 && site < nv) {
+                const float v0 = sum, v1 = other;
+                const float mx = fmaxf(v0, v1);
+                const float e0 = expf(v0 - mx), e1 = expf(v1 - mx);
+                const float p1 = e1 / (e0 + e1);
+                int q = (int)(255 * p1);
+                q = q > 255 ? 255 : q;
+                const int dst = sites ? sites[s0 + site].uidx : s0 + site;
+                logits[2 * (size_t)dst] = v0;
+                logits[2 * (size_t)dst + 1] = v1;
+                prob[dst] = p1;
+                ml[dst] = (uint8_t)q;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// =================================================================================================
+// launchers
+// =================================================================================================
+void launch_prep(hipStream_t st, const uint8_t* raw, const ReadDesc* reads, const Chunk* chunks, int n_chunks,
+                 int ctx_mask, uint8_t* bases, uint32_t* kin, int32_t* chunk_counts, int32_t* err) {
+    if (n_chunks <= 0) return;
+    hipLaunchKernelGGL(prep_kernel, dim3(n_chunks), dim3(PREP_THREADS), 0, st, raw, reads, chunks, ctx_mask, bases, kin,
+                       chunk_counts, err);
+}
+
+void launch_scan(hipStream_t st, const int32_t* chunk_counts, int n_chunks, int32_t* chunk_offs, int32_t* totals) {
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, chunk_counts, n_chunks, chunk_offs, totals);
+}
+
+void launch_emit(hipStream_t st, const ReadDesc* reads, const Chunk* chunks, int n_chunks, int ctx_mask,
+                 const uint8_t* bases, const int32_t* chunk_offs, const int32_t* totals, USite* usites,
+                 uint8_t* utag, Site* csites) {
+    if (n_chunks <= 0) return;
+    hipLaunchKernelGGL(emit_kernel, dim3(n_chunks), dim3(PREP_THREADS), 0, st, reads, chunks, ctx_mask, bases,
+                       chunk_offs, totals, usites, utag, csites);
+}
+
+void launch_windows(hipStream_t st, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
+                    const uint32_t* kin, const BnTables* bn, float* out, int grid) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(window_kernel, dim3(min(n, grid)), dim3(256), 0, st, sites, n, reads, bases, kin, bn, out);
+}
+
+void launch_front(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
+                  const uint32_t* kin, const float* windows, const CtxWeights& w, float* act4, int grid, float* dbg,
+                  int dbg_layer) {
+    if (n <= 0) return;
+    const dim3 g(min(n, grid)), b(256);
+    const bool raw = windows == nullptr;
+    if (k1 == 11) {
+        if (raw) hipLaunchKernelGGL((front_kernel<11, true>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer);
+        else hipLaunchKernelGGL((front_kernel<11, false>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer);
+    } else {
+        if (raw) hipLaunchKernelGGL((front_kernel<13, true>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer);
+        else hipLaunchKernelGGL((front_kernel<13, false>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer);
+    }
+}
+
+void launch_tail(hipStream_t st, const float* act4, int n, const CtxWeights& w, const Site* sites, float* logits,
+                 float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer) {
+    if (n <= 0) return;
+    const int groups = (n + TAIL_SITES - 1) / TAIL_SITES;
+    hipLaunchKernelGGL(tail_kernel, dim3(min(groups, grid)), dim3(256), 0, st, act4, n, w, sites, logits, p, ml, dbg,
+                       dbg_layer);
+}
+
+size_t front_lds_bytes(int k1) { return sizeof(float) * (k1 == 11 ? Geo<11>::LDS_FLOATS : Geo<13>::LDS_FLOATS); }
+size_t tail_lds_bytes() { return sizeof(float) * TailGeo::LDS_FLOATS; }
+
+}  // namespace hm

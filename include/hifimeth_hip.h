@@ -1,0 +1,120 @@
+/*
+ * hifimeth_hip.h -- C ABI of libhifimeth_hip.so, the MI355X (gfx950) engine for the
+ * `hifimeth call` hot path: per-read CpG/CHG/CHH site scan -> 401x8 kinetics window -> CNN ->
+ * per-site 5mC probability.
+ *
+ * The reference has no plugin/FFI layer; this library sits where three C++ classes of the
+ * reference sit inside its worker thread (src/app/hifimeth/mod_main.cpp:145-262):
+ *
+ *   ns_mods::ModModels                  (mod_main.cpp:18-99)         -> hm_create / hm_destroy
+ *   ns_mods::EvalKmerFeaturesGenerator  (eval_kmer_features.hpp:13-49)
+ *       init(bam1_t*)                                                -> hm_submit_read
+ *       extract_{cpg,chg,chh}_samples()                              -> hm_run, hm_scan_sites
+ *       get_next_sample_features()                                   -> hm_windows
+ *   ns_mods::ModBatch                   (mod_batch.hpp:12-43)
+ *       call_mods_for_one_read / call_current_batch                  -> hm_run, hm_cnn_logits
+ *       results appended to std::vector<MolMethyCall>                -> hm_fetch / hm_drain
+ *
+ * Plain pointers and sizes only; every call returns >= 0 on success and a negative HM_E* code
+ * on failure (the reference abort()s instead: src/corelib/hbn_aux.hpp:100-104), with the message
+ * available from hm_last_error().  An engine is driven by one host thread at a time.
+ */
+#ifndef HIFIMETH_HIP_H
+#define HIFIMETH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HM_CTX_CPG 0
+#define HM_CTX_CHG 1
+#define HM_CTX_CHH 2
+#define HM_CTX_ALL 3 /* only as the `ctx` argument of hm_num_sites */
+
+#define HM_OK 0
+#define HM_EINVAL (-1)  /* bad argument                                             */
+#define HM_EMODEL (-2)  /* model file missing / ill-formed (mod_main.cpp:40-52)     */
+#define HM_EDEVICE (-3) /* HIP runtime error or no gfx950 device                    */
+#define HM_EDATA (-4)   /* illegal base nibble in a read (bam_info.cpp:100-121)     */
+#define HM_ESTATE (-5)  /* call out of order (e.g. hm_fetch before hm_run)          */
+#define HM_ENOMEM (-6)
+
+typedef struct hm_engine hm_engine_t;
+
+/* One call = the reference's MolMethyCall (src/corelib/5mc_motif_finder.hpp:8-14) plus the
+ * context and the float probability the reference never exposes (needed for the |dp| check). */
+typedef struct {
+    int32_t read_id;     /* qid: the id given to hm_submit_read                           */
+    int32_t qoff;        /* forward-strand offset of the cytosine (of the G for strand 1) */
+    uint8_t strand;      /* 0 = FWD, 1 = REV (src/corelib/hbn_aux.hpp:60-63)              */
+    uint8_t ctx;         /* HM_CTX_*                                                      */
+    uint8_t scaled_prob; /* min(255, (int)(255 * p))  (mod_batch.cpp:46-64)               */
+    uint8_t reserved;
+    float p;             /* softmax(logits)[1]                                            */
+} hm_call_t;
+
+/* Accumulated device time per kernel class since the last hm_reset_timing (HIP events on the
+ * engine's stream; only collected when option "timing" is 1). */
+typedef struct {
+    double prep_ms, scan_ms, emit_ms, window_ms;
+    double front_ms[3], tail_ms[3];
+    int64_t prep_launches, scan_launches, emit_launches, window_launches;
+    int64_t front_launches[3], tail_launches[3];
+    int64_t front_sites[3]; /* sites processed by the timed front launches */
+    int64_t window_sites;
+} hm_timing_t;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+/* model_dir holds {CpG,CHG,CHH}.hmw (flat fp32 container written from the reference's
+ * models/{CpG,CHG,CHH}.onnx) or the .onnx files themselves; ctx_mask bit c enables context c
+ * (the reference's -c cpg,chg,chh: mod_options.cpp:61-134); device = HIP device ordinal.   */
+int hm_create(hm_engine_t** out, const char* model_dir, int ctx_mask, int device);
+void hm_destroy(hm_engine_t* e);
+const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a failed hm_create */
+/* options: "min_read_size" (-l, default 1000), "timing" (0/1), "sub_batch_sites" (front/tail
+ * launch granularity, default 65536) */
+int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
+
+/* ---- staging: the EvalKmerFeaturesGenerator::init seam ----------------------------------- */
+/* Copies one read into the pinned staging slab exactly as the BAM record stores it: 4-bit
+ * packed SEQ, and the fi/fp/ri/rp B-arrays with element width 1 (B:C codev1) or 2 (B:S frames).
+ * A NULL array means the tag is missing.  Returns 1 if the read was accepted, 0 if it is passed
+ * through uncalled (l_qseq < min_read_size or a missing tag: mod_main.cpp:189-196), < 0 on error.
+ * The caller keeps ownership of all pointers.                                                */
+int hm_submit_read(hm_engine_t* e, int32_t read_id, int32_t l_qseq, int32_t flag, const uint8_t* seq4,
+                   const void* fi, int fi_width, const void* fp, int fp_width, const void* ri, int ri_width,
+                   const void* rp, int rp_width);
+int hm_clear(hm_engine_t* e); /* forget the staged / resident batch */
+
+/* ---- execution --------------------------------------------------------------------------- */
+int hm_upload(hm_engine_t* e); /* staged slab -> HBM (async on the engine stream)              */
+int hm_run(hm_engine_t* e);    /* scanner + window builder + CNN over the resident batch        */
+int hm_sync(hm_engine_t* e);   /* wait for everything queued; reports device-side data errors   */
+int64_t hm_num_sites(hm_engine_t* e, int ctx); /* after hm_run: the reference's processed_*_samples */
+/* D2H of the results of the last hm_run, ordered by (read submission order, strand, qoff) -- the
+ * order build_one_mod_bam needs (mod_main.cpp:217-251).  Returns the number of calls written. */
+int64_t hm_fetch(hm_engine_t* e, hm_call_t* out, int64_t cap);
+/* convenience: hm_flush = hm_upload + hm_run ; hm_drain = hm_sync + hm_fetch + hm_clear */
+int hm_flush(hm_engine_t* e);
+int64_t hm_drain(hm_engine_t* e, hm_call_t* out, int64_t cap);
+
+/* ---- seams used by the parity tests and the feature-extraction roofline ------------------- */
+/* extract_*_samples: site list of one context after hm_run, in (read, qoff) order */
+int64_t hm_scan_sites(hm_engine_t* e, int ctx, int32_t* read_id, int32_t* qoff, uint8_t* strand, int64_t cap);
+/* get_next_sample_features: raw 401x8 fp32 windows of sites [first, first+n) of context ctx;
+ * out_host may be NULL (device-only run for timing) */
+int hm_windows(hm_engine_t* e, int ctx, int64_t first, int64_t n, float* out_host);
+/* ModBatch::call_current_batch on caller-supplied windows [n][401][8] (host memory) */
+int hm_cnn_logits(hm_engine_t* e, int ctx, const float* windows, int64_t n, float* logits, float* p, uint8_t* ml);
+/* post-ReLU channels-last activations of conv `layer` (1..8) for one window (debug / tests) */
+int64_t hm_debug_layer(hm_engine_t* e, int ctx, const float* window, int layer, float* out, int64_t cap);
+
+int hm_get_timing(hm_engine_t* e, hm_timing_t* t);
+int hm_reset_timing(hm_engine_t* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

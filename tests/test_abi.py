@@ -1,0 +1,83 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/hifimeth_hip.h declares; no compute call is made (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "hifimeth_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hm_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from hifimeth_amd import _lib
+    L = _lib.lib()
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/hifimeth_hip.h but not exported"
+    assert set(names) == set(L._hm_symbols), set(names) ^ set(L._hm_symbols)
+
+
+def test_struct_layout_matches_header():
+    from hifimeth_amd import _lib
+    from hifimeth_amd.caller import CALL_DTYPE
+    assert ctypes.sizeof(_lib.hm_call_t) == 16 and CALL_DTYPE.itemsize == 16
+    assert CALL_DTYPE.fields["p"][1] == 12 and CALL_DTYPE.fields["scaled_prob"][1] == 10
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product must fail loudly, never fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hifimeth_amd import HifimethError, MethylationCaller
+    with pytest.raises(HifimethError):
+        MethylationCaller()
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "hifimeth_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "hm_oracle" not in txt and "oracle/" not in txt.replace("the oracle", ""), f
+
+
+def test_parse_contexts():
+    from hifimeth_amd import parse_contexts
+    assert parse_contexts("cpg,chg,chh") == 7 and parse_contexts("CpG") == 1 and parse_contexts("chh,chg") == 6
+    with pytest.raises(ValueError):
+        parse_contexts("cpg,foo")
+
+
+def test_onnx_reader_roundtrip(tmp_path):
+    """Python ONNX/.hmw reader: .hmw round trip is lossless and geometry matches SURVEY.md 8(a9)."""
+    from hifimeth_amd.onnx_weights import load_hmw, save_hmw
+    w = load_hmw(os.path.join(ROOT, "hifimeth_amd", "weights", "CHH.hmw"))
+    assert w.k1 == 13 and w.n_params() == 268866 and w.macs_per_site() == 11440640
+    p = str(tmp_path / "x.hmw")
+    save_hmw(w, p)
+    assert open(p, "rb").read() == open(os.path.join(ROOT, "hifimeth_amd", "weights", "CHH.hmw"), "rb").read()
+    w = load_hmw(os.path.join(ROOT, "hifimeth_amd", "weights", "CpG.hmw"))
+    assert w.k1 == 11 and w.n_params() == 266818 and w.macs_per_site() == 11148800
+
+
+def test_synth_density():
+    from hifimeth_amd.synth import expected_sites_per_base, synth_reads
+    from oracle import hm_oracle as O
+    reads = synth_reads(6, seed=5, gc=0.36, frac_missing=0, frac_short=0)
+    bases = sum(r.l_qseq for r in reads)
+    sites = 0
+    for r in reads:
+        f = O.decode(r)
+        sites += sum(len(O.scan(f, c)) for c in range(3))
+    assert abs(sites / bases - expected_sites_per_base(0.36)) < 0.02

@@ -1,0 +1,306 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+Runs on the GPU box only:  python -m pytest tests -m gpu -x -q
+Bars: site lists and windows bit-exact; probabilities |dp| <= 1e-4 (fp32 path, BASELINE.json
+north_star); ML bytes within 1 LSB.  Ordered so that a failure localises: scan -> windows ->
+CNN layers -> logits -> whole path."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, WEIGHTS
+from hifimeth_amd.synth import Read, read_from_ascii, synth_reads
+
+pytestmark = pytest.mark.gpu
+
+DP_TOL = 1e-4  # north_star: |dp| <= 1e-4 vs the fp32 CPU path
+
+
+@pytest.fixture(scope="module")
+def mc():
+    from hifimeth_amd import MethylationCaller
+    m = MethylationCaller(device=0, timing=True)
+    yield m
+    m.close()
+
+
+def _kin(L, rng, wide=False):
+    if wide:
+        return [np.clip(np.rint(rng.gamma(2.0, 30.0, L)), 0, 2000).astype(np.uint16) for _ in range(4)]
+    return [np.clip(np.rint(rng.gamma(2.0, 12.0, L)), 0, 255).astype(np.uint8) for _ in range(4)]
+
+
+def _mixed_reads():
+    rng = np.random.default_rng(17)
+    reads = synth_reads(5, seed=31, median_len=2600, sigma=0.3, frac_wide=0.4, frac_short=0, frac_missing=0, frac_n=0.003)
+    # exact-minimum length, a chunk-boundary length, stored-as-reverse read, homopolymers
+    for L, flag in ((1000, 4), (1024, 4), (1025, 16), (2049, 0)):
+        seq = "".join("ACGT"[i] for i in rng.choice(4, L))
+        reads.append(read_from_ascii(seq.encode(), *_kin(L, rng, wide=(L == 1025)), flag=flag))
+    reads.append(read_from_ascii(b"C" * 1100, *_kin(1100, rng)))
+    reads.append(read_from_ascii(b"G" * 1030, *_kin(1030, rng)))
+    reads.append(read_from_ascii(b"CG" * 600, *_kin(1200, rng)))
+    reads.append(read_from_ascii((b"ACGTNCGNNCCGCANGCTGGGNAAGNTTGCNAACCNGG" * 30), *_kin(38 * 30, rng)))
+    return reads
+
+
+def test_scan_sites_match_oracle(mc, oracle):
+    reads = _mixed_reads()
+    mc.clear()
+    assert mc.submit_all(reads) == len(reads)
+    mc.upload()
+    mc.run()
+    total = 0
+    for c in range(3):
+        rid, qoff, strand = mc.scan_sites(c)
+        want_r, want_q, want_s = [], [], []
+        for i, rd in enumerate(reads):
+            fwd = oracle.decode(rd)
+            offs = np.sort(oracle.scan(fwd, c))       # device order is (read, qoff); reference emission differs for CHH
+            want_r += [i] * len(offs)
+            want_q += offs.tolist()
+            want_s += [1 if fwd[o:o + 1] == b"G" else 0 for o in offs]
+        assert np.array_equal(rid, want_r) and np.array_equal(qoff, want_q) and np.array_equal(strand, want_s), c
+        assert mc.num_sites(c) == len(want_q)
+        total += len(want_q)
+    assert mc.num_sites(3) == total > 0
+
+
+def test_scan_golden_reference_lists(mc):
+    """Device scanner against the lists the reference's own C++ scanner produced (tests/golden/scan.json)."""
+    rng = np.random.default_rng(3)
+    recs = [r for r in json.load(open(os.path.join(GOLDEN, "scan.json")))]
+    mc.set_option("min_read_size", 1)
+    try:
+        mc.clear()
+        for i, r in enumerate(recs):
+            L = len(r["seq"])
+            assert mc.submit(i, read_from_ascii(r["seq"].encode(), *_kin(L, rng), flag=r["flag"]))
+        mc.upload()
+        mc.run()
+        for c, key in enumerate(("cpg", "chg", "chh")):
+            rid, qoff, _ = mc.scan_sites(c)
+            for i, r in enumerate(recs):
+                assert qoff[rid == i].tolist() == sorted(r[key]), (key, i)
+    finally:
+        mc.set_option("min_read_size", 1000)
+        mc.clear()
+
+
+def test_windows_bit_exact_vs_oracle(mc, oracle):
+    reads = _mixed_reads()
+    mc.clear()
+    mc.submit_all(reads)
+    mc.upload()
+    mc.run()
+    for c in range(3):
+        rid, qoff, strand = mc.scan_sites(c)
+        n = len(qoff)
+        pick = np.unique(np.concatenate([np.arange(min(n, 40)), np.arange(max(0, n - 40), n),
+                                         np.random.default_rng(c).integers(0, n, 60)]))
+        got_all = mc.windows(c)
+        assert got_all.shape == (n, 401, 8)
+        for i in pick:
+            rd = reads[rid[i]]
+            w, s = oracle.window(rd, oracle.decode(rd), int(qoff[i]))
+            assert s == strand[i]
+            assert np.array_equal(got_all[i], w), (c, i, rid[i], qoff[i])
+
+
+def test_windows_golden_reference_python(mc):
+    """Device windows against windows assembled by the reference's training/sample_dataset.py."""
+    z = np.load(os.path.join(GOLDEN, "windows.npz"))
+    reads = [Read("g", int(z[f"len_{i}"]), 4, z[f"seq4_{i}"], z[f"fi_{i}"], z[f"fp_{i}"], z[f"ri_{i}"], z[f"rp_{i}"])
+             for i in range(int(z["n_reads"]))]
+    mc.set_option("min_read_size", 1)
+    try:
+        mc.clear()
+        mc.submit_all(reads)
+        mc.upload()
+        mc.run()
+        found = 0
+        for c in range(3):
+            rid, qoff, strand = mc.scan_sites(c)
+            if len(qoff) == 0:
+                continue
+            wins = mc.windows(c)
+            key = {(int(r), int(q)): k for k, (r, q) in enumerate(zip(rid, qoff))}
+            for g in range(len(z["qoff"])):
+                k = key.get((int(z["read"][g]), int(z["qoff"][g])))
+                if k is None:
+                    continue
+                assert strand[k] == z["strand"][g]
+                assert np.array_equal(wins[k], z["windows"][g])
+                found += 1
+        # every golden site is a C or G; those that are a site of some context must all have matched
+        assert found >= len(z["qoff"]) // 2
+    finally:
+        mc.set_option("min_read_size", 1000)
+        mc.clear()
+
+
+@pytest.mark.parametrize("ctx,name", [(0, "CpG"), (2, "CHH")])
+def test_cnn_layers_vs_oracle(mc, oracle, ctx, name):
+    z = np.load(os.path.join(GOLDEN, f"cnn_{name}.npz"))
+    om = oracle.Model(os.path.join(WEIGHTS, name + ".hmw"))
+    for widx in (0, 5, 61):
+        w = z["windows"][widx]
+        for layer in range(1, 9):
+            want = om.layer(w, layer)
+            got = mc.debug_layer(ctx, w, layer)
+            assert got.shape == want.shape, (layer, got.shape, want.shape)
+            err = np.abs(got - want).max()
+            assert err <= 1e-4 * max(1.0, np.abs(want).max()), (name, widx, layer, err)
+
+
+@pytest.mark.parametrize("ctx,name", [(0, "CpG"), (2, "CHH")])
+def test_cnn_logits_vs_reference_torchscript(mc, oracle, ctx, name):
+    z = np.load(os.path.join(GOLDEN, f"cnn_{name}.npz"))
+    lg, p, ml = mc.cnn_logits(ctx, z["windows"])
+    assert np.abs(lg - z["logits"]).max() < 5e-5
+    pr, mlr = oracle.softmax(z["logits"])
+    assert np.abs(p - pr).max() <= DP_TOL
+    assert np.abs(ml.astype(int) - mlr.astype(int)).max() <= 1
+
+
+def test_cnn_logits_chg_and_ragged_batches(mc, oracle, oracle_models):
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 8, 9, 300):
+        w = np.zeros((n, 401, 8), np.float32)
+        w[:, :, :4] = np.eye(4, dtype=np.float32)[rng.integers(0, 4, (n, 401))]
+        w[:, :, 4:] = rng.gamma(2.0, 0.03, (n, 401, 4)).astype(np.float32)
+        lg, p, ml = mc.cnn_logits(1, w)
+        want = oracle_models[1].logits(w)
+        assert np.abs(lg - want).max() < 5e-5
+        pw, _ = oracle.softmax(want)
+        assert np.abs(p - pw).max() <= DP_TOL
+
+
+def _check_calls(calls, reads, oracle, oracle_models, mask):
+    worst, nml, n = 0.0, 0, 0
+    for rid, rd in enumerate(reads):
+        got = calls[calls["read_id"] == rid]
+        if not rd.has_kinetics() or rd.l_qseq < 1000:
+            assert len(got) == 0
+            continue
+        want = oracle.call_read(oracle_models, mask, rd)
+        order = np.lexsort((want["qoff"], want["strand"]))     # (strand, qoff): FWD calls then REV calls
+        assert len(got) == len(order)
+        assert np.array_equal(got["qoff"], want["qoff"][order])
+        assert np.array_equal(got["strand"], want["strand"][order])
+        assert np.array_equal(got["ctx"], want["ctx"][order])
+        dp = np.abs(got["p"] - want["p"][order])
+        worst = max(worst, float(dp.max(initial=0)))
+        dml = np.abs(got["scaled_prob"].astype(int) - want["ml"][order].astype(int))
+        assert dml.max(initial=0) <= 1
+        nml += int((dml > 0).sum())
+        n += len(got)
+    assert worst <= DP_TOL, worst
+    return n, nml, worst
+
+
+def test_end_to_end_all_contexts(mc, oracle, oracle_models):
+    reads = _mixed_reads() + synth_reads(4, seed=77, median_len=1800, sigma=0.2, frac_short=0.5, frac_missing=0.3)
+    calls = mc.call(reads)
+    n, nml, worst = _check_calls(calls, reads, oracle, oracle_models, 7)
+    assert n > 3000
+    # per-strand calls strictly increasing in qoff (asserted downstream by build_mod_bam.cpp:138,156)
+    for rid in np.unique(calls["read_id"]):
+        for s in (0, 1):
+            q = calls["qoff"][(calls["read_id"] == rid) & (calls["strand"] == s)]
+            assert (np.diff(q) > 0).all()
+    print(f"e2e: {n} sites, max|dp|={worst:.2e}, ML bytes differing by 1: {nml}")
+
+
+@pytest.mark.parametrize("spec,mask", [("cpg", 1), ("chg,chh", 6)])
+def test_context_masks(oracle, oracle_models, spec, mask):
+    from hifimeth_amd import MethylationCaller
+    reads = synth_reads(3, seed=5, median_len=1500, sigma=0.1, frac_short=0, frac_missing=0)
+    with MethylationCaller(contexts=spec) as m:
+        calls = m.call(reads)
+        assert set(np.unique(calls["ctx"]).tolist()) <= {c for c in range(3) if mask >> c & 1}
+        _check_calls(calls, reads, oracle, oracle_models, mask)
+
+
+def test_empty_and_skipped(mc):
+    mc.clear()
+    mc.upload()
+    mc.run()
+    assert mc.num_sites(3) == 0 and len(mc.fetch()) == 0
+    rng = np.random.default_rng(1)
+    short = read_from_ascii(b"ACGT" * 100, *_kin(400, rng))
+    missing = read_from_ascii(b"ACGT" * 300, *_kin(1200, rng))
+    missing.rp = None
+    badlen = read_from_ascii(b"ACGT" * 300, *_kin(1200, rng))
+    badlen.fi = badlen.fi[:-1]
+    mc.clear()
+    assert not mc.submit(0, short) and not mc.submit(1, missing) and not mc.submit(2, badlen)
+    mc.upload()
+    mc.run()
+    assert len(mc.fetch()) == 0
+    mc.clear()
+
+
+def test_illegal_base_is_reported(mc):
+    from hifimeth_amd import HifimethError
+    rng = np.random.default_rng(2)
+    rd = read_from_ascii(b"ACGT" * 300, *_kin(1200, rng))
+    rd.seq4 = rd.seq4.copy()
+    rd.seq4[10] = 0x31  # nibble 3 ('M') is not A/C/G/T/N: the reference aborts (bam_info.cpp:100-121)
+    mc.clear()
+    mc.submit(0, rd)
+    mc.upload()
+    mc.run()
+    with pytest.raises(HifimethError):
+        mc.sync()
+    mc.clear()
+
+
+def test_idempotent_rerun_and_sub_batches(mc):
+    """Same resident batch run twice, and with a tiny sub-batch size, gives identical bytes."""
+    reads = synth_reads(3, seed=9, median_len=2000, sigma=0.1, frac_short=0, frac_missing=0)
+    mc.clear()
+    mc.submit_all(reads)
+    mc.upload()
+    mc.run()
+    a = mc.fetch().copy()
+    mc.run()
+    b = mc.fetch().copy()
+    mc.set_option("sub_batch_sites", 64)
+    mc.run()
+    c = mc.fetch().copy()
+    mc.set_option("sub_batch_sites", 65536)
+    mc.clear()
+    assert a.tobytes() == b.tobytes() == c.tobytes() and len(a) > 0
+
+
+def test_full_size_properties(mc):
+    """BASELINE-size batch (too big for the oracle): size-independent properties.
+    count identity, strand/ctx consistency with the sequence, sortedness, probability range, and
+    equality of results between one big batch and the same reads split over two batches."""
+    reads = synth_reads(48, seed=123, frac_missing=0.02)
+    calls = mc.call(reads)
+    assert len(calls) > 100_000
+    assert np.isfinite(calls["p"]).all() and (calls["p"] >= 0).all() and (calls["p"] <= 1).all()
+    assert (calls["scaled_prob"] == np.minimum(255, (255 * calls["p"]).astype(np.int64))).all()
+    key = calls["read_id"].astype(np.int64) * 4 + calls["strand"]
+    assert (np.diff(key) >= 0).all()
+    same = np.diff(key) == 0
+    assert (np.diff(calls["qoff"])[same] > 0).all()
+    for rid in (0, 17, 47):
+        rd = reads[rid]
+        sub = calls[calls["read_id"] == rid]
+        if not rd.has_kinetics():
+            assert len(sub) == 0
+            continue
+        seq = np.frombuffer(rd.ascii(), np.uint8)
+        assert (seq[sub["qoff"][sub["strand"] == 0]] == ord("C")).all()
+        assert (seq[sub["qoff"][sub["strand"] == 1]] == ord("G")).all()
+        assert (sub["ctx"][sub["strand"] == 1] == 2).all()
+        nxt = seq[np.minimum(sub["qoff"][sub["ctx"] == 0] + 1, len(seq) - 1)]
+        assert (nxt == ord("G")).all()
+    half = len(reads) // 2
+    a = mc.call(reads[:half], first_id=0)
+    b = mc.call(reads[half:], first_id=half)
+    assert np.concatenate([a, b]).tobytes() == calls.tobytes()
