@@ -30,11 +30,26 @@ MAC_FRONT = {0: 197 * 128 * 88 + 99 * 128 * 384 + 50 * 128 * 384 + 25 * 96 * 384
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
 
 
+def host_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    env = os.environ.get("HM_CPU_THREADS")
+    if env:
+        return max(1, int(env))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(reads, budget_s=15.0):
     """The CPU oracle (port of the reference path) timed on this node's host cores, bounded sample."""
     from oracle import hm_oracle as O
     O.build()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     models = [O.Model(os.path.join(ROOT, "hifimeth_amd", "weights", n + ".hmw")) for n in ("CpG", "CHG", "CHH")]
     t0 = time.perf_counter()
     sites = 0
