@@ -76,18 +76,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     from hifimeth_amd import MethylationCaller
+    from hifimeth_amd import dist as hmdist
     from hifimeth_amd.synth import synth_reads
+
+    rank, local_rank, world = hmdist.env_world()
+    dist = hmdist.init_process_group("nccl") if world > 1 else None
 
     reads = synth_reads(args.reads, seed=20250220 + rank, gc=0.36)
     mc = MethylationCaller(device=local_rank, timing=True)
@@ -118,16 +112,7 @@ def main():
     tm = mc.timing()
     bases = sum(r.l_qseq for r in reads if r.has_kinetics() and r.l_qseq >= 1000)
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_max = float(t.item())
-        s = torch.tensor([float(sites_step)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        sites_all = float(s.item())
-    else:
-        dt_max, sites_all = dt, float(sites_step)
+    sites_all, dt_max = hmdist.job_throughput(dist, sites_step, dt, device="cuda" if dist is not None else "cpu")
 
     if rank == 0:
         front_ms = sum(tm["front_ms"])

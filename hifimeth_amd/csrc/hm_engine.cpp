@@ -631,6 +631,17 @@ int64_t hm_debug_layer(hm_engine_t* e, int ctx, const float* window, int layer, 
     return nf;
 }
 
+int hm_convert_model(const char* src_path, const char* dst_hmw_path) {
+    if (!src_path || !dst_hmw_path) return fail(nullptr, HM_EINVAL, "hm_convert_model: bad argument");
+    const std::string src(src_path);
+    HostModel m;
+    std::string msg;
+    const bool is_hmw = src.size() > 4 && src.compare(src.size() - 4, 4, ".hmw") == 0;
+    if (!(is_hmw ? load_hmw(src, m, msg) : load_onnx(src, m, msg))) return fail(nullptr, HM_EMODEL, msg);
+    if (!save_hmw(m, dst_hmw_path, msg)) return fail(nullptr, HM_EMODEL, msg);
+    return HM_OK;
+}
+
 int hm_get_timing(hm_engine_t* e, hm_timing_t* t) {
     if (!e || !t) return HM_EINVAL;
     *t = e->acc;

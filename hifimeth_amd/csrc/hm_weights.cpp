@@ -349,9 +349,42 @@ bool load_onnx(const std::string& path, HostModel& m, std::string& err) {
     return finish_geometry(m, path, err);
 }
 
+bool save_hmw(const HostModel& m, const std::string& path, std::string& err) {
+    std::ofstream f(path, std::ios::binary);
+    if (!f) {
+        err = "cannot write " + path;
+        return false;
+    }
+    auto put = [&](const void* p, size_t n) { f.write(reinterpret_cast<const char*>(p), (std::streamsize)n); };
+    const int32_t hdr[4] = {KMER, FEATS, m.k1, 8};
+    int32_t kern[8];
+    for (int i = 0; i < 8; ++i) kern[i] = m.kernel[i];
+    put("HMW1", 4);
+    put(hdr, sizeof hdr);
+    put(kChannels, 9 * sizeof(int32_t));
+    put(kern, sizeof kern);
+    put(&m.bn_eps, 4);
+    put(m.bn_gamma, 32);
+    put(m.bn_beta, 32);
+    put(m.bn_mean, 32);
+    put(m.bn_var, 32);
+    for (int i = 0; i < 8; ++i) {
+        put(m.conv_w[i].data(), m.conv_w[i].size() * 4);
+        put(m.conv_b[i].data(), m.conv_b[i].size() * 4);
+    }
+    put(m.fc1_w.data(), m.fc1_w.size() * 4);
+    put(m.fc1_b.data(), m.fc1_b.size() * 4);
+    put(m.fc2_w.data(), m.fc2_w.size() * 4);
+    put(m.fc2_b.data(), m.fc2_b.size() * 4);
+    if (!f) {
+        err = "write error on " + path;
+        return false;
+    }
+    return true;
+}
+
 bool load_model_dir(const char* dir, const char* name, HostModel& out, std::string& err) {
     const std::string base = std::string(dir) + "/" + name;
-    std::vector<uint8_t> probe;
     if (std::ifstream(base + ".hmw", std::ios::binary)) return load_hmw(base + ".hmw", out, err);
     if (std::ifstream(base + ".onnx", std::ios::binary)) return load_onnx(base + ".onnx", out, err);
     err = "model not found: " + base + ".{hmw,onnx}";

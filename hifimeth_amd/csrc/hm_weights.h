@@ -30,6 +30,7 @@ bool load_model_dir(const char* dir, const char* name, HostModel& out, std::stri
 bool load_hmw(const std::string& path, HostModel& out, std::string& err);
 bool load_onnx(const std::string& path, HostModel& out, std::string& err);
 PackedModel pack_model(const HostModel& m);
+bool save_hmw(const HostModel& m, const std::string& path, std::string& err);
 
 extern const int kChannels[9];
 

@@ -111,6 +111,11 @@ int hm_cnn_logits(hm_engine_t* e, int ctx, const float* windows, int64_t n, floa
 /* post-ReLU channels-last activations of conv `layer` (1..8) for one window (debug / tests) */
 int64_t hm_debug_layer(hm_engine_t* e, int ctx, const float* window, int layer, float* out, int64_t cap);
 
+/* Model-file utility (no GPU needed): read <src> (.onnx in either shipped dialect, or .hmw) and write
+ * the flat fp32 .hmw container.  The same reader serves hm_create, so a model_dir holding the
+ * reference's own CpG.onnx / CHG.onnx / CHH.onnx (mod_main.cpp:76,85,94) works unchanged. */
+int hm_convert_model(const char* src_path, const char* dst_hmw_path);
+
 int hm_get_timing(hm_engine_t* e, hm_timing_t* t);
 int hm_reset_timing(hm_engine_t* e);
 

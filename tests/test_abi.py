@@ -81,3 +81,34 @@ def test_synth_density():
         f = O.decode(r)
         sites += sum(len(O.scan(f, c)) for c in range(3))
     assert abs(sites / bases - expected_sites_per_base(0.36)) < 0.02
+
+
+def test_cxx_onnx_reader_matches_python_reader(tmp_path):
+    """The C++ model reader of the product (both ONNX dialects) against the committed .hmw files,
+    which the Python reader produced from the same ONNX files.  Needs /root/reference (build container)."""
+    ref = "/root/reference/models"
+    if not os.path.isdir(ref):
+        pytest.skip("reference models absent")
+    from hifimeth_amd import _lib
+    L = _lib.lib()
+    for ctx in ("CpG", "CHG", "CHH"):
+        out = str(tmp_path / (ctx + ".hmw"))
+        assert L.hm_convert_model(os.path.join(ref, ctx + ".onnx").encode(), out.encode()) == 0, L.hm_last_error(None)
+        assert open(out, "rb").read() == open(os.path.join(ROOT, "hifimeth_amd", "weights", ctx + ".hmw"), "rb").read()
+    assert L.hm_convert_model(b"/nonexistent.onnx", b"/tmp/x.hmw") < 0
+    assert b"cannot read" in L.hm_last_error(None)
+
+
+def test_cxx_hmw_roundtrip_and_rejects_garbage(tmp_path):
+    from hifimeth_amd import _lib
+    L = _lib.lib()
+    src = os.path.join(ROOT, "hifimeth_amd", "weights", "CHG.hmw")
+    out = str(tmp_path / "o.hmw")
+    assert L.hm_convert_model(src.encode(), out.encode()) == 0
+    assert open(out, "rb").read() == open(src, "rb").read()
+    bad = tmp_path / "bad.hmw"
+    bad.write_bytes(open(src, "rb").read()[:1000])
+    assert L.hm_convert_model(str(bad).encode(), out.encode()) < 0
+    junk = tmp_path / "junk.onnx"
+    junk.write_bytes(os.urandom(4096))
+    assert L.hm_convert_model(str(junk).encode(), out.encode()) < 0
