@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=96, help="reads per GPU batch (~15 kb each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (e.g. front_waves=8)")
     args = ap.parse_args()
 
     from hifimeth_amd import MethylationCaller
@@ -85,6 +86,9 @@ def main():
 
     reads = synth_reads(args.reads, seed=20250220 + rank, gc=0.36)
     mc = MethylationCaller(device=local_rank, timing=True)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        mc.set_option(k, int(v))
     mc.submit_all(reads)
     mc.upload()          # inputs resident in HBM before the timed region
     mc.sync()

@@ -67,6 +67,7 @@ def lib():
         "hm_cnn_logits": (C.c_int, [vp, C.c_int, vp, i64, vp, vp, vp]),
         "hm_debug_layer": (i64, [vp, C.c_int, vp, C.c_int, vp, i64]),
         "hm_convert_model": (C.c_int, [cp, cp]),
+        "hm_get_stamps": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
         "hm_get_timing": (C.c_int, [vp, C.POINTER(hm_timing_t)]),
         "hm_reset_timing": (C.c_int, [vp]),
     }

@@ -173,6 +173,11 @@ class MethylationCaller:
         chans = (8, 128, 128, 128, 96, 96, 96, 64, 64)[layer]
         return out[:n].reshape(-1, chans).copy()
 
+    def stamps(self) -> list:
+        buf = (C.c_uint64 * 32)()
+        n = self._check(self._L.hm_get_stamps(self._h, buf, 32), "hm_get_stamps")
+        return [int(buf[i]) for i in range(n)]
+
     def timing(self, reset: bool = False) -> dict:
         t = _lib.hm_timing_t()
         self._check(self._L.hm_get_timing(self._h, C.byref(t)), "hm_get_timing")

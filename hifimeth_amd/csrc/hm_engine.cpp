@@ -96,6 +96,9 @@ struct hm_engine {
     int ctx_mask = 7;
     int min_read_size = 1000;  // mod_options.cpp:10
     int64_t sub_batch = 65536;
+    int front_waves = 8;
+    bool stamps_on = false;
+    std::vector<unsigned long long> stamp_sum;
     bool timing = false;
     hipStream_t stream = nullptr;
     DeviceModel model[3];
@@ -110,7 +113,7 @@ struct hm_engine {
 
     // device
     DevBuf d_raw, d_reads, d_chunks, d_bases, d_kin, d_counts, d_offs, d_totals, d_err;
-    DevBuf d_usites, d_utag, d_csites, d_logits, d_p, d_ml, d_act4, d_win, d_dbg;
+    DevBuf d_usites, d_utag, d_csites, d_logits, d_p, d_ml, d_act4, d_win, d_dbg, d_stamps;
     int32_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int32_t* h_totals = nullptr;  // pinned
     int32_t* h_err = nullptr;     // pinned
@@ -214,6 +217,18 @@ void ensure_site_buffers(hm_engine* e, int64_t n) {
     e->d_ml.reserve(nn);
 }
 
+// diagnostic: sum the per-wave phase stamps of the front launch that was just queued
+void accumulate_stamps(hm_engine* e) {
+    const int ns = front_stamp_slots();
+    const size_t n = (size_t)e->num_cu * 8 * ns;
+    std::vector<unsigned long long> h(n);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(h.data(), e->d_stamps.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(e->d_stamps.p, 0, n * sizeof(unsigned long long)));
+    e->stamp_sum.resize((size_t)ns, 0);
+    for (size_t i = 0; i < n; ++i) e->stamp_sum[i % ns] += h[i];
+}
+
 // front + tail over `n` sites of one context, in sub-batches that bound the act4 hand-off buffer
 void run_cnn(hm_engine* e, int ctx, const Site* sites, const float* windows, int64_t n, float* dbg, int dbg_layer) {
     const DeviceModel& dm = e->model[ctx];
@@ -226,7 +241,9 @@ void run_cnn(hm_engine* e, int ctx, const Site* sites, const float* windows, int
         {
             Span sp(e, K_FRONT0 + ctx, m);
             launch_front(e->stream, dm.k1, s_off, m, e->d_reads.as<ReadDesc>(), e->d_bases.as<uint8_t>(),
-                         e->d_kin.as<uint32_t>(), w_off, dm.w, e->d_act4.as<float>(), e->num_cu, dbg, dbg_layer);
+                         e->d_kin.as<uint32_t>(), w_off, dm.w, e->d_act4.as<float>(), e->num_cu, dbg, dbg_layer,
+                         e->front_waves, e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr);
+            if (e->stamps_on) accumulate_stamps(e);
             sp.end();
         }
         {
@@ -298,7 +315,7 @@ void hm_destroy(hm_engine_t* e) {
     for (auto& m : e->model) m.params.release();
     for (DevBuf* b : {&e->d_raw, &e->d_reads, &e->d_chunks, &e->d_bases, &e->d_kin, &e->d_counts, &e->d_offs,
                       &e->d_totals, &e->d_err, &e->d_usites, &e->d_utag, &e->d_csites, &e->d_logits, &e->d_p,
-                      &e->d_ml, &e->d_act4, &e->d_win, &e->d_dbg})
+                      &e->d_ml, &e->d_act4, &e->d_win, &e->d_dbg, &e->d_stamps})
         b->release();
     e->slab.release();
     if (e->h_totals) (void)hipHostFree(e->h_totals);
@@ -319,7 +336,22 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
     const std::string k(key);
     if (k == "min_read_size") e->min_read_size = (int)value;
     else if (k == "timing") e->timing = value != 0;
-    else if (k == "sub_batch_sites") {
+    else if (k == "stamps") {
+        e->stamps_on = value != 0;
+        if (e->stamps_on) {
+            try {
+                const size_t bytes = (size_t)e->num_cu * 8 * front_stamp_slots() * sizeof(unsigned long long);
+                e->d_stamps.reserve(bytes);
+                HIP_TRY(hipMemset(e->d_stamps.p, 0, bytes));
+                e->stamp_sum.assign((size_t)front_stamp_slots(), 0);
+            } catch (const HipErr& h) {
+                return fail_hip(e, h);
+            }
+        }
+    } else if (k == "front_waves") {
+        if (value != 4 && value != 8) return fail(e, HM_EINVAL, "front_waves must be 4 or 8");
+        e->front_waves = (int)value;
+    } else if (k == "sub_batch_sites") {
         if (value < TAIL_SITES) return fail(e, HM_EINVAL, "sub_batch_sites too small");
         e->sub_batch = value / TAIL_SITES * TAIL_SITES;
     } else return fail(e, HM_EINVAL, "unknown option " + k);
@@ -640,6 +672,13 @@ int hm_convert_model(const char* src_path, const char* dst_hmw_path) {
     if (!(is_hmw ? load_hmw(src, m, msg) : load_onnx(src, m, msg))) return fail(nullptr, HM_EMODEL, msg);
     if (!save_hmw(m, dst_hmw_path, msg)) return fail(nullptr, HM_EMODEL, msg);
     return HM_OK;
+}
+
+int hm_get_stamps(hm_engine_t* e, uint64_t* out, int cap) {
+    if (!e || !out) return HM_EINVAL;
+    const int n = (int)std::min<size_t>(e->stamp_sum.size(), (size_t)std::max(cap, 0));
+    for (int i = 0; i < n; ++i) out[i] = e->stamp_sum[(size_t)i];
+    return n;
 }
 
 int hm_get_timing(hm_engine_t* e, hm_timing_t* t) {

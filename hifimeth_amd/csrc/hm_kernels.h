@@ -26,7 +26,8 @@ void launch_windows(hipStream_t st, const Site* sites, int n, const ReadDesc* re
 //        -> bn0 -> conv1..conv4 -> act4[n][25][96]
 void launch_front(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
                   const uint32_t* kin, const float* windows, const CtxWeights& w, float* act4, int grid,
-                  float* dbg, int dbg_layer);
+                  float* dbg, int dbg_layer, int waves, unsigned long long* stamps);
+int front_stamp_slots();
 // tail: conv5..conv8, fc1, fc2, softmax for 8 sites per workgroup pass.
 // results go to index sites[i].uidx (or i when sites == nullptr).
 void launch_tail(hipStream_t st, const float* act4, int n, const CtxWeights& w, const Site* sites, float* logits,

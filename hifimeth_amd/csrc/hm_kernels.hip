@@ -12,6 +12,7 @@
 #include "hm_kernels.h"
 
 #include <type_traits>
+#include <utility>
 
 namespace hm {
 
@@ -309,17 +310,19 @@ __global__ __launch_bounds__(256) void window_kernel(const Site* __restrict__ si
 // with one zero row in front of and behind every site (the conv's own padding), so the im2col row
 // of output position p is the contiguous slice starting at physical row 2p:
 //     A[m][kk] = lds[site*ISS + (2p + ROW0 + tap)*IRS + c]
-// Row strides are == 1 (mod 16) floats, which makes the 16-row x 2-k ds_read_b32 pattern of the
-// A fragment (lane l: row l&15, k = l>>4) bank-conflict free.
+// Row strides are 4 x odd floats (12 / 132 / 100 / 68): rows stay 16-byte aligned and the ds_read_b128
+// pattern of the A fragment (lane l: row l&15, 4 consecutive K elements chosen by l>>4) is bank-conflict free.
 // Weights are pre-packed on the host in fragment order [n-tile][k-group of 16][lane][4]: lane l of
-// n-tile nt holds Wk[kg*16 + 4*s + (l>>4)][nt*16 + (l&15)] in component s, so every lane fetches the
-// B operands of four consecutive k-steps with one 16-byte load straight from L2.
+// n-tile nt holds Wk[kg*16 + 4*(l>>4) + s][nt*16 + (l&15)] in component s (the same k permutation as the
+// A side), so every lane fetches the B operands of four k-steps with one 16-byte load straight from L2.
 // The 4 waves of a workgroup tile the output as WM x WN blocks of (MTW x NTW) 16x16 tiles.
 
-template <int S_, int CIN_, int KT_, int COUT_, int LOUT_, int IRS_, int ISS_, int ROW0_, int WM_, int WN_>
+template <int NW_, int S_, int CIN_, int KT_, int COUT_, int LOUT_, int IRS_, int ISS_, int ROW0_, int WM_, int WN_,
+          int BR_ = 2>
 struct Conv {
-    static constexpr int S = S_, CIN = CIN_, KT = KT_, COUT = COUT_, LOUT = LOUT_, IRS = IRS_, ISS = ISS_;
+    static constexpr int NW = NW_, S = S_, CIN = CIN_, KT = KT_, COUT = COUT_, LOUT = LOUT_, IRS = IRS_, ISS = ISS_;
     static constexpr int ROW0 = ROW0_, WM = WM_, WN = WN_;
+    static constexpr int BR = BR_;  // B-fragment register ring: BR-1 k-groups in flight from L2
     static constexpr int M = S * LOUT;
     static constexpr int MT = (M + 15) / 16;
     static constexpr int NT = COUT / 16;
@@ -327,13 +330,36 @@ struct Conv {
     static constexpr int NTW = NT / WN;
     static constexpr int K = KT * CIN;
     static constexpr int KG = K / 16;
-    static_assert(K % 16 == 0 && COUT % 16 == 0 && NT % WN == 0 && WM * WN == 4 && CIN % 4 == 0, "bad conv geometry");
+    static_assert(K % 16 == 0 && COUT % 16 == 0 && NT % WN == 0 && WM * WN <= NW && CIN % 4 == 0, "bad conv geometry");
+    static_assert(CIN % 16 == 0 || 16 % CIN == 0, "a 16-wide k-group must not straddle taps unevenly");
+    static_assert(IRS % 4 == 0 && ISS % 4 == 0, "A fragments are fetched with 16-byte LDS reads");
+    static_assert(BR >= 2 && KG >= BR - 1 && KG >= 1, "bad pipeline depth");
 
-    template <class Epi>
-    static __device__ __forceinline__ void run(const float* __restrict__ in, const float* __restrict__ wfrag, Epi epi) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int wm = wave / WN, wn = wave % WN;
+    // LDS offset (floats) of the first element of k-group kg relative to physical row 2p+ROW0, channel 0
+    static __device__ __forceinline__ int group_off(int kg) {
+        const int kk = kg * 16;
+        const int tap = kk / CIN;
+        return tap * IRS + (kk - tap * CIN);
+    }
+
+    struct NoMark {
+        __device__ __forceinline__ void operator()(int) const {}
+    };
+
+    template <class Epi, class Mark = NoMark>
+    static __device__ __forceinline__ void run(const float* __restrict__ in, const float* __restrict__ wfrag, Epi epi,
+                                               Mark mark = Mark{}) {
+        // launder the thread id so that hipcc does not hoist this layer's address arithmetic out of the
+        // persistent site loop (it otherwise keeps every layer's invariants live and spills)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        if (WM * WN < NW && wave >= WM * WN) return;  // spare waves of a small layer (no barrier inside run)
+        const int wm = WM == 1 ? 0 : wave / WN, wn = WM == 1 ? wave : wave % WN;
         const int li = lane & 15, lk = lane >> 4;
+        // k permutation inside a 16-wide k-group: MFMA k-step s, k-index lk  <->  K element 4*lk + s.
+        // Lane (li, lk) therefore owns 4 consecutive K elements = one 16-byte LDS read per k-group.
+        const int lk_off = CIN >= 16 ? 4 * lk : ((4 * lk) / CIN) * IRS + (4 * lk) % CIN;
 
         int aoff[MTW];
 #pragma unroll
@@ -341,104 +367,125 @@ struct Conv {
             int m = (wm * MTW + i) * 16 + li;
             m = m < M ? m : M - 1;  // rows of the ragged last tile re-read the last valid row (discarded later)
             const int site = m / LOUT, p = m - site * LOUT;
-            aoff[i] = site * ISS + (2 * p + ROW0) * IRS + lk;
+            aoff[i] = site * ISS + (2 * p + ROW0) * IRS + lk_off;
         }
+        // Operands are swapped (weights as the MFMA A operand, activations as B) so that the C/D layout
+        // gives every lane 4 CONSECUTIVE output channels of one position: D[row = cout = 4*lk + r][col = pos li].
+        // The bias is folded into the accumulator init; the epilogue stores 16 bytes per tile.
         f32x4 acc[MTW][NTW];
 #pragma unroll
-        for (int i = 0; i < MTW; ++i)
+        for (int j = 0; j < NTW; ++j) {
+            const float4 bz = *reinterpret_cast<const float4*>(epi.bias + (wn * NTW + j) * 16 + 4 * lk);
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < MTW; ++i) acc[i][j] = f32x4{bz.x, bz.y, bz.z, bz.w};
+        }
 
         const float4* wp = reinterpret_cast<const float4*>(wfrag) + (size_t)(wn * NTW) * KG * 64 + lane;
-        float4 bq[2][NTW];
-        float a[2][MTW];
+        float4 bq[BR][NTW];
+        float4 a[2][MTW];
+        // prologue: BR-1 k-groups of B and one k-group of A in flight
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) bq[0][j] = wp[(size_t)(j * KG) * 64];
+        for (int r = 0; r < BR - 1; ++r)
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) a[0][i] = in[aoff[i]];  // k-step 0: tap 0, channel 0
+            for (int j = 0; j < NTW; ++j) bq[r][j] = wp[(size_t)(j * KG + r) * 64];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) a[0][i] = *reinterpret_cast<const float4*>(in + aoff[i]);
 
-        auto group = [&](auto cb_tag, const int kg) __attribute__((always_inline)) {
-            constexpr int CB = decltype(cb_tag)::value;
-            if (kg + 1 < KG) {
+        // One k-group = 4 MFMA k-steps.  Software pipeline pinned with sched_barrier so that hipcc keeps
+        // it: B fragments BR-1 groups ahead (global/L2), A fragments one group ahead (LDS, ds_read_b128).
+        auto group = [&](auto rb_tag, auto ra_tag, const int kg) __attribute__((always_inline)) {
+            constexpr int RB = decltype(rb_tag)::value;
+            constexpr int RA = decltype(ra_tag)::value;
+            if (kg + BR - 1 < KG) {
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) bq[CB ^ 1][j] = wp[(size_t)(j * KG + kg + 1) * 64];
+                for (int j = 0; j < NTW; ++j) bq[(RB + BR - 1) % BR][j] = wp[(size_t)(j * KG + kg + BR - 1) * 64];
             }
+            if (kg + 1 < KG) {
+                const float* gn = in + group_off(kg + 1);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int ks = kg * 4 + s;
-                if (ks + 1 < KG * 4) {  // fetch the A fragments of the next k-step while this one multiplies
-                    const int kk = (ks + 1) * 4;
-                    const int tap = kk / CIN;
-                    const int ko = tap * IRS + (kk - tap * CIN);
+                for (int i = 0; i < MTW; ++i) a[RA ^ 1][i] = *reinterpret_cast<const float4*>(gn + aoff[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < MTW; ++i) a[(s + 1) & 1][i] = in[aoff[i] + ko];
-                }
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < MTW; ++i)
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) {
-                        const float bv = s == 0 ? bq[CB][j].x : s == 1 ? bq[CB][j].y : s == 2 ? bq[CB][j].z : bq[CB][j].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][i], bv, acc[i][j], 0, 0, 0);
+                        const float av = s == 0 ? a[RA][i].x : s == 1 ? a[RA][i].y : s == 2 ? a[RA][i].z : a[RA][i].w;
+                        const float bv = s == 0 ? bq[RB][j].x : s == 1 ? bq[RB][j].y : s == 2 ? bq[RB][j].z : bq[RB][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
                     }
-            }
+            __builtin_amdgcn_sched_barrier(0);
         };
+        mark(0);
+        // main loop unrolled by lcm(BR, 2) so that every ring index is a compile-time constant
+        constexpr int UN = BR % 2 == 0 ? BR : 2 * BR;
         int kg = 0;
 #pragma nounroll
-        for (; kg + 1 < KG; kg += 2) {
-            group(std::integral_constant<int, 0>{}, kg);
-            group(std::integral_constant<int, 1>{}, kg + 1);
+        for (; kg + UN <= KG; kg += UN) {
+            [&]<int... R>(std::integer_sequence<int, R...>) __attribute__((always_inline)) {
+                (group(std::integral_constant<int, R % BR>{}, std::integral_constant<int, R % 2>{}, kg + R), ...);
+            }(std::make_integer_sequence<int, UN>{});
         }
-        if (KG & 1) group(std::integral_constant<int, 0>{}, KG - 1);
+        [&]<int... R>(std::integer_sequence<int, R...>) __attribute__((always_inline)) {
+            ((R < KG % UN ? group(std::integral_constant<int, R % BR>{}, std::integral_constant<int, R % 2>{}, KG - KG % UN + R)
+                          : (void)0), ...);
+        }(std::make_integer_sequence<int, UN>{});
+        mark(1);
 
 #pragma unroll
-        for (int i = 0; i < MTW; ++i)
+        for (int i = 0; i < MTW; ++i) {
+            const int m = (wm * MTW + i) * 16 + li;  // this lane's output position (row of the GEMM)
+            // tiles that lie completely inside M need no predicate (compile-time when WM == 1)
+            const bool full = WM == 1 ? (i + 1) * 16 <= M : false;
+            if (full || m < M) {
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) epi(wm * MTW + i, wn * NTW + j, acc[i][j]);
+                for (int j = 0; j < NTW; ++j) epi(m, (wn * NTW + j) * 16 + 4 * lk, acc[i][j]);
+            }
+        }
     }
 };
 
-// bias + ReLU, result to LDS channels-last with row stride ORS / site stride OSS (physical row p+1).
-template <int LOUT, int M, int ORS, int OSS>
+// diagnostic builds only: shader-clock stamp (cdna_hip_programming.md section 7, "In-kernel stamps")
+__device__ __forceinline__ unsigned long long hm_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+constexpr int N_STAMP = 20;
+
+// ReLU (bias already in the accumulator); 4 consecutive channels of position m -> LDS channels-last with
+// row stride ORS / site stride OSS (physical row p+1)
+template <int LOUT, int ORS, int OSS>
 struct EpiLds {
     float* out;
     const float* __restrict__ bias;
-    __device__ __forceinline__ void operator()(int mt, int nt, const f32x4& acc) const {
-        const int lane = threadIdx.x & 63;
-        const int col = nt * 16 + (lane & 15);
-        const float bv = bias[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = mt * 16 + (lane >> 4) * 4 + r;  // C/D layout: row = (lane>>4)*4 + reg, col = lane&15
-            if (m < M) {
-                const int site = m / LOUT, p = m - site * LOUT;
-                out[site * OSS + (p + 1) * ORS + col] = fmaxf(acc[r] + bv, 0.f);
-            }
-        }
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        const int site = OSS == 0 ? 0 : m / LOUT;
+        const int p = OSS == 0 ? m : m - site * LOUT;
+        *reinterpret_cast<float4*>(out + site * OSS + (p + 1) * ORS + col) =
+            make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
     }
 };
 
-// bias + ReLU, result to global channels-last [m][COUT]
-template <int M, int COUT>
+// ReLU, result to global channels-last [m][COUT]
+template <int COUT>
 struct EpiGlobal {
     float* __restrict__ out;
     const float* __restrict__ bias;
-    int m_valid;
-    __device__ __forceinline__ void operator()(int mt, int nt, const f32x4& acc) const {
-        const int lane = threadIdx.x & 63;
-        const int col = nt * 16 + (lane & 15);
-        const float bv = bias[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = mt * 16 + (lane >> 4) * 4 + r;
-            if (m < M && m < m_valid) out[(size_t)m * COUT + col] = fmaxf(acc[r] + bv, 0.f);
-        }
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        *reinterpret_cast<float4*>(out + (size_t)m * COUT + col) =
+            make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
     }
 };
 
 // zero the padding rows (physical rows 0 and LOUT+1) of S stacked sites
 template <int S, int LOUT, int COUT, int ORS, int OSS>
 __device__ __forceinline__ void zero_pad_rows(float* out) {
-    for (int i = threadIdx.x; i < S * 2 * COUT; i += 256) {
+    for (int i = threadIdx.x; i < S * 2 * COUT; i += blockDim.x) {
         const int site = i / (2 * COUT), rem = i - site * 2 * COUT;
         const int which = rem / COUT, c = rem - which * COUT;
         out[site * OSS + (which ? (LOUT + 1) : 0) * ORS + c] = 0.f;
@@ -447,7 +494,7 @@ __device__ __forceinline__ void zero_pad_rows(float* out) {
 
 template <int L, int C, int RS>
 __device__ __forceinline__ void dump_lds(const float* buf, float* __restrict__ dbg) {
-    for (int i = threadIdx.x; i < L * C; i += 256) dbg[i] = buf[(i / C + 1) * RS + (i % C)];
+    for (int i = threadIdx.x; i < L * C; i += blockDim.x) dbg[i] = buf[(i / C + 1) * RS + (i % C)];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -461,29 +508,50 @@ struct Geo {
     static constexpr int L4 = (L3 - 1) / 2 + 1;         // 25 / 25
     static_assert(L4 == C4_LEN, "conv4 length");
     static constexpr int KT1 = (K1 * FEATS + 15) / 16 * 2;  // taps incl. zero-weight K padding: 12 / 14
-    static constexpr int WRS = 9;                            // window row stride (floats)
+    static constexpr int WRS = 12;                           // window row stride (floats, 16-B aligned rows)
     static constexpr int WROWS = 2 * (L1 - 1) + KT1;         // physical window rows touched by conv1
-    static constexpr int RS = 129;                           // row stride of the 128-channel activations
+    static constexpr int RS = 132;                           // row stride of the 128-channel activations
     static constexpr int A1 = (L1 + 2) * RS, A2 = (L2 + 2) * RS, A3 = (L3 + 2) * RS, WIN = WROWS * WRS;
     static constexpr int BUFA = A1 > A3 ? A1 : A3;
     static constexpr int BUFB = WIN > A2 ? WIN : A2;
     static constexpr int LDS_FLOATS = BUFA + BUFB;
 };
 
-template <int K1, bool RAW>
-__global__ __launch_bounds__(256) void front_kernel(const Site* __restrict__ sites, int n_sites,
+template <int K1, bool RAW, int NW, bool STAMP = false>
+__global__ __launch_bounds__(NW * 64) void front_kernel(const Site* __restrict__ sites, int n_sites,
                                                      const ReadDesc* __restrict__ reads,
                                                      const uint8_t* __restrict__ bases,
                                                      const uint32_t* __restrict__ kin,
                                                      const float* __restrict__ windows, CtxWeights W,
-                                                     float* __restrict__ act4, float* __restrict__ dbg, int dbg_layer) {
+                                                     float* __restrict__ act4, float* __restrict__ dbg, int dbg_layer,
+                                                     unsigned long long* __restrict__ stamps) {
     using G = Geo<K1>;
-    __shared__ float smem[G::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[G::LDS_FLOATS];
     float* bufA = smem;
     float* bufB = smem + G::BUFA;
     const BnTables* __restrict__ bn = W.bn;
 
+    unsigned long long tacc[N_STAMP];
+    unsigned long long tprev = 0;
+    if (STAMP) {
+#pragma unroll
+        for (int i = 0; i < N_STAMP; ++i) tacc[i] = 0;
+    }
+    auto mk = [&](int ph) __attribute__((always_inline)) {
+        if (STAMP) {
+            const unsigned long long t_ = hm_stamp();
+            tacc[ph] += t_ - tprev;
+            tprev = t_;
+        }
+    };
+#define HM_MARK(PH)                               \
+    if (STAMP) {                                  \
+        const unsigned long long t_ = hm_stamp(); \
+        tacc[PH] += t_ - tprev;                   \
+        tprev = t_;                               \
+    }
     for (int s = blockIdx.x; s < n_sites; s += gridDim.x) {
+        if (STAMP) tprev = hm_stamp();
         // ---- window rows -> bufB, bn0 applied.  physical row pr holds window row pr-1; rows
         // outside [0,401) are the conv's zero padding (and the zero-weight K padding of conv1).
         if (RAW) {
@@ -491,7 +559,7 @@ __global__ __launch_bounds__(256) void front_kernel(const Site* __restrict__ sit
             const int L = reads[st.read_idx].len;
             const int64_t bo = reads[st.read_idx].base_off;
             const int rev = bases[bo + st.qoff] == 2;
-            for (int pr = threadIdx.x; pr < G::WROWS; pr += 256) {
+            for (int pr = threadIdx.x; pr < G::WROWS; pr += NW * 64) {
                 const int w = pr - 1;
                 float v[8];
                 if (w < 0 || w >= KMER) {
@@ -522,40 +590,56 @@ __global__ __launch_bounds__(256) void front_kernel(const Site* __restrict__ sit
             }
         } else {
             const float* __restrict__ src = windows + (size_t)s * (KMER * FEATS);
-            for (int i = threadIdx.x; i < G::WROWS * 8; i += 256) {
+            for (int i = threadIdx.x; i < G::WROWS * 8; i += NW * 64) {
                 const int pr = i >> 3, c = i & 7, w = pr - 1;
                 float v = 0.f;
                 if (w >= 0 && w < KMER) v = (src[w * 8 + c] - bn->mean[c]) / bn->sd[c] * bn->gamma[c] + bn->beta[c];
                 bufB[pr * G::WRS + c] = v;
             }
         }
+        HM_MARK(0)
         __syncthreads();
+        HM_MARK(1)
 
         // conv1: window (bufB) -> bufA
-        Conv<1, 8, G::KT1, 128, G::L1, G::WRS, 0, 0, 1, 4>::run(
-            bufB, W.wfrag[0], EpiLds<G::L1, G::L1, G::RS, 0>{bufA, W.bias[0]});
+        Conv<NW, 1, 8, G::KT1, 128, G::L1, G::WRS, 0, 0, 1, NW>::run(
+            bufB, W.wfrag[0], EpiLds<G::L1, G::RS, 0>{bufA, W.bias[0]}, [&](int k) __attribute__((always_inline)) { mk(2 + k); });
+        HM_MARK(4)
         zero_pad_rows<1, G::L1, 128, G::RS, 0>(bufA);
         __syncthreads();
+        HM_MARK(5)
         if (dbg && dbg_layer == 1 && s == 0) dump_lds<G::L1, 128, G::RS>(bufA, dbg);
 
         // conv2: bufA -> bufB
-        Conv<1, 128, 3, 128, G::L2, G::RS, 0, 0, 1, 4>::run(
-            bufA, W.wfrag[1], EpiLds<G::L2, G::L2, G::RS, 0>{bufB, W.bias[1]});
+        Conv<NW, 1, 128, 3, 128, G::L2, G::RS, 0, 0, 1, NW>::run(
+            bufA, W.wfrag[1], EpiLds<G::L2, G::RS, 0>{bufB, W.bias[1]}, [&](int k) __attribute__((always_inline)) { mk(6 + k); });
+        HM_MARK(8)
         zero_pad_rows<1, G::L2, 128, G::RS, 0>(bufB);
         __syncthreads();
+        HM_MARK(9)
         if (dbg && dbg_layer == 2 && s == 0) dump_lds<G::L2, 128, G::RS>(bufB, dbg);
 
         // conv3: bufB -> bufA
-        Conv<1, 128, 3, 128, G::L3, G::RS, 0, 0, 1, 4>::run(
-            bufB, W.wfrag[2], EpiLds<G::L3, G::L3, G::RS, 0>{bufA, W.bias[2]});
+        Conv<NW, 1, 128, 3, 128, G::L3, G::RS, 0, 0, 1, NW, 3>::run(
+            bufB, W.wfrag[2], EpiLds<G::L3, G::RS, 0>{bufA, W.bias[2]}, [&](int k) __attribute__((always_inline)) { mk(10 + k); });
+        HM_MARK(12)
         zero_pad_rows<1, G::L3, 128, G::RS, 0>(bufA);
         __syncthreads();
+        HM_MARK(13)
         if (dbg && dbg_layer == 3 && s == 0) dump_lds<G::L3, 128, G::RS>(bufA, dbg);
 
         // conv4: bufA -> act4[s] in HBM (hand-off to the tail kernel)
-        Conv<1, 128, 3, C4_CH, G::L4, G::RS, 0, 0, 2, 2>::run(
-            bufA, W.wfrag[3], EpiGlobal<G::L4, C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3], G::L4});
+        Conv<NW, 1, 128, 3, C4_CH, G::L4, G::RS, 0, 0, 2, (NW == 4 ? 2 : 3), 4>::run(
+            bufA, W.wfrag[3], EpiGlobal<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]}, [&](int k) __attribute__((always_inline)) { mk(14 + k); });
+        HM_MARK(16)
         __syncthreads();  // bufA/bufB are rewritten by the next site
+        HM_MARK(17)
+    }
+#undef HM_MARK
+    if (STAMP && (threadIdx.x & 63) == 0) {
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * N_STAMP;
+#pragma unroll
+        for (int i = 0; i < N_STAMP; ++i) o[i] = tacc[i];
     }
 }
 
@@ -565,7 +649,7 @@ __global__ __launch_bounds__(256) void front_kernel(const Site* __restrict__ sit
 struct TailGeo {
     static constexpr int S = TAIL_SITES;
     static constexpr int L4 = 25, L5 = 13, L6 = 7, L7 = 4, L8 = 2;
-    static constexpr int RS96 = 97, RS64 = 65, HRS = 257;
+    static constexpr int RS96 = 100, RS64 = 68, HRS = 260;
     static constexpr int IN_SS = (L4 + 2) * RS96, C5_SS = (L5 + 2) * RS96, C6_SS = (L6 + 2) * RS96;
     static constexpr int C7_SS = (L7 + 2) * RS64, C8_SS = (L8 + 2) * RS64;
     static constexpr int BUF0 = S * IN_SS;  // also holds conv6 / conv8 outputs
@@ -580,7 +664,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ act
                                                     float* __restrict__ dbg, int dbg_layer) {
     using T = TailGeo;
     constexpr int S = T::S;
-    __shared__ float smem[T::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[T::LDS_FLOATS];
     float* buf0 = smem;
     float* buf1 = smem + T::BUF0;
 
@@ -602,34 +686,34 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ act
         zero_pad_rows<S, T::L4, 96, T::RS96, T::IN_SS>(buf0);
         __syncthreads();
 
-        Conv<S, 96, 3, 96, T::L5, T::RS96, T::IN_SS, 0, 2, 2>::run(
-            buf0, W.wfrag[4], EpiLds<T::L5, S * T::L5, T::RS96, T::C5_SS>{buf1, W.bias[4]});
+        Conv<4, S, 96, 3, 96, T::L5, T::RS96, T::IN_SS, 0, 2, 2>::run(
+            buf0, W.wfrag[4], EpiLds<T::L5, T::RS96, T::C5_SS>{buf1, W.bias[4]});
         zero_pad_rows<S, T::L5, 96, T::RS96, T::C5_SS>(buf1);
         __syncthreads();
         if (dbg && dbg_layer == 5 && g == 0) dump_lds<T::L5, 96, T::RS96>(buf1, dbg);
 
-        Conv<S, 96, 3, 96, T::L6, T::RS96, T::C5_SS, 0, 2, 2>::run(
-            buf1, W.wfrag[5], EpiLds<T::L6, S * T::L6, T::RS96, T::C6_SS>{buf0, W.bias[5]});
+        Conv<4, S, 96, 3, 96, T::L6, T::RS96, T::C5_SS, 0, 2, 2>::run(
+            buf1, W.wfrag[5], EpiLds<T::L6, T::RS96, T::C6_SS>{buf0, W.bias[5]});
         zero_pad_rows<S, T::L6, 96, T::RS96, T::C6_SS>(buf0);
         __syncthreads();
         if (dbg && dbg_layer == 6 && g == 0) dump_lds<T::L6, 96, T::RS96>(buf0, dbg);
 
-        Conv<S, 96, 3, 64, T::L7, T::RS96, T::C6_SS, 0, 2, 2>::run(
-            buf0, W.wfrag[6], EpiLds<T::L7, S * T::L7, T::RS64, T::C7_SS>{buf1, W.bias[6]});
+        Conv<4, S, 96, 3, 64, T::L7, T::RS96, T::C6_SS, 0, 2, 2>::run(
+            buf0, W.wfrag[6], EpiLds<T::L7, T::RS64, T::C7_SS>{buf1, W.bias[6]});
         zero_pad_rows<S, T::L7, 64, T::RS64, T::C7_SS>(buf1);
         __syncthreads();
         if (dbg && dbg_layer == 7 && g == 0) dump_lds<T::L7, 64, T::RS64>(buf1, dbg);
 
-        Conv<S, 64, 3, 64, T::L8, T::RS64, T::C7_SS, 0, 1, 4>::run(
-            buf1, W.wfrag[7], EpiLds<T::L8, S * T::L8, T::RS64, T::C8_SS>{buf0, W.bias[7]});
+        Conv<4, S, 64, 3, 64, T::L8, T::RS64, T::C7_SS, 0, 1, 4>::run(
+            buf1, W.wfrag[7], EpiLds<T::L8, T::RS64, T::C8_SS>{buf0, W.bias[7]});
         __syncthreads();
         if (dbg && dbg_layer == 8 && g == 0) dump_lds<T::L8, 64, T::RS64>(buf0, dbg);
 
         // fc1 as a 2-tap "conv" over the two positions of conv8's output: A[site][l*64 + c] = rows 1,2.
         // (weights are packed in that k order from fc1.weight[o][c*2 + l], the channel-major flatten
         //  of model_cnn.py:79).  Output h[site][256] with row stride HRS: (p+1)*ORS with ORS = 0.
-        Conv<S, 64, 2, 256, 1, T::RS64, T::C8_SS, 1, 1, 4>::run(
-            buf0, W.wfrag[8], EpiLds<1, S, 0, T::HRS>{buf1, W.bias[8]});
+        Conv<4, S, 64, 2, 256, 1, T::RS64, T::C8_SS, 1, 1, 4>::run(
+            buf0, W.wfrag[8], EpiLds<1, 0, T::HRS>{buf1, W.bias[8]});
         __syncthreads();
 
         // fc2 + softmax (mod_batch.cpp:46-64): 16 lanes per site = 2 outputs x 8 partial sums
@@ -693,18 +777,26 @@ void launch_windows(hipStream_t st, const Site* sites, int n, const ReadDesc* re
 
 void launch_front(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
                   const uint32_t* kin, const float* windows, const CtxWeights& w, float* act4, int grid, float* dbg,
-                  int dbg_layer) {
+                  int dbg_layer, int waves, unsigned long long* stamps) {
     if (n <= 0) return;
-    const dim3 g(min(n, grid)), b(256);
+    const dim3 g(min(n, grid));
     const bool raw = windows == nullptr;
-    if (k1 == 11) {
-        if (raw) hipLaunchKernelGGL((front_kernel<11, true>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer);
-        else hipLaunchKernelGGL((front_kernel<11, false>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer);
+#define HM_FRONT(K1, RAW, NW, ST)                                                                                     \
+    hipLaunchKernelGGL((front_kernel<K1, RAW, NW, ST>), g, dim3(NW * 64), 0, st, sites, n, reads, bases, kin, windows, \
+                       w, act4, dbg, dbg_layer, stamps)
+    if (stamps && raw && waves == 8) {  // diagnostic build of the production configuration
+        if (k1 == 11) HM_FRONT(11, true, 8, true); else HM_FRONT(13, true, 8, true);
+    } else if (waves == 8) {
+        if (k1 == 11) { if (raw) HM_FRONT(11, true, 8, false); else HM_FRONT(11, false, 8, false); }
+        else { if (raw) HM_FRONT(13, true, 8, false); else HM_FRONT(13, false, 8, false); }
     } else {
-        if (raw) hipLaunchKernelGGL((front_kernel<13, true>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer);
-        else hipLaunchKernelGGL((front_kernel<13, false>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer);
+        if (k1 == 11) { if (raw) HM_FRONT(11, true, 4, false); else HM_FRONT(11, false, 4, false); }
+        else { if (raw) HM_FRONT(13, true, 4, false); else HM_FRONT(13, false, 4, false); }
     }
+#undef HM_FRONT
 }
+
+int front_stamp_slots() { return N_STAMP; }
 
 void launch_tail(hipStream_t st, const float* act4, int n, const CtxWeights& w, const Site* sites, float* logits,
                  float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer) {

@@ -401,7 +401,7 @@ static void pack_layer(std::vector<float>& blob, int K_real, int K_pad, int COUT
         for (int kg = 0; kg < KG; ++kg)
             for (int lane = 0; lane < 64; ++lane)
                 for (int s = 0; s < 4; ++s) {
-                    const int kk = kg * 16 + s * 4 + (lane >> 4);
+                    const int kk = kg * 16 + (lane >> 4) * 4 + s;  // k permutation: lane group l>>4 owns 4 consecutive K
                     const int co = nt * 16 + (lane & 15);
                     blob.push_back(kk < K_real ? wk(kk, co) : 0.f);
                 }

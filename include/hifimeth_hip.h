@@ -74,7 +74,7 @@ int hm_create(hm_engine_t** out, const char* model_dir, int ctx_mask, int device
 void hm_destroy(hm_engine_t* e);
 const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a failed hm_create */
 /* options: "min_read_size" (-l, default 1000), "timing" (0/1), "sub_batch_sites" (front/tail
- * launch granularity, default 65536) */
+ * launch granularity, default 65536), "front_waves" (4 or 8 waves per front workgroup), "stamps" (diagnostic) */
 int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
 
 /* ---- staging: the EvalKmerFeaturesGenerator::init seam ----------------------------------- */
@@ -115,6 +115,10 @@ int64_t hm_debug_layer(hm_engine_t* e, int ctx, const float* window, int layer, 
  * the flat fp32 .hmw container.  The same reader serves hm_create, so a model_dir holding the
  * reference's own CpG.onnx / CHG.onnx / CHH.onnx (mod_main.cpp:76,85,94) works unchanged. */
 int hm_convert_model(const char* src_path, const char* dst_hmw_path);
+
+/* diagnostic (option "stamps" = 1): shader-clock cycles per phase of the front kernel, summed over
+ * all waves of the launches since the option was set; returns the number of slots written */
+int hm_get_stamps(hm_engine_t* e, uint64_t* out, int cap);
 
 int hm_get_timing(hm_engine_t* e, hm_timing_t* t);
 int hm_reset_timing(hm_engine_t* e);

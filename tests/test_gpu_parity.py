@@ -223,6 +223,18 @@ def test_context_masks(oracle, oracle_models, spec, mask):
         _check_calls(calls, reads, oracle, oracle_models, mask)
 
 
+@pytest.mark.parametrize("waves", [4, 8])
+def test_front_wave_configs(mc, oracle, oracle_models, waves):
+    reads = synth_reads(2, seed=11, median_len=1600, sigma=0.1, frac_short=0, frac_missing=0)
+    mc.set_option("front_waves", waves)
+    try:
+        calls = mc.call(reads)
+        n, _, worst = _check_calls(calls, reads, oracle, oracle_models, 7)
+        assert n > 500
+    finally:
+        mc.set_option("front_waves", 4)
+
+
 def test_empty_and_skipped(mc):
     mc.clear()
     mc.upload()
