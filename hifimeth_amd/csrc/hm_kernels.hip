@@ -550,55 +550,58 @@ __global__ __launch_bounds__(NW * 64) void front_kernel(const Site* __restrict__
         tacc[PH] += t_ - tprev;                   \
         tprev = t_;                               \
     }
-    for (int s = blockIdx.x; s < n_sites; s += gridDim.x) {
-        if (STAMP) tprev = hm_stamp();
-        // ---- window rows -> bufB, bn0 applied.  physical row pr holds window row pr-1; rows
-        // outside [0,401) are the conv's zero padding (and the zero-weight K padding of conv1).
+    // window rows of site s -> bufB with bn0 applied, by threads [t0, t0 + nt) of the workgroup.
+    // physical row pr holds window row pr-1; rows outside [0,401) are the conv's zero padding (and the
+    // zero-weight K padding of conv1).
+    auto build_window = [&](const int s, const int t, const int nt) __attribute__((always_inline)) {
         if (RAW) {
             const Site st = sites[s];
             const int L = reads[st.read_idx].len;
             const int64_t bo = reads[st.read_idx].base_off;
             const int rev = bases[bo + st.qoff] == 2;
-            for (int pr = threadIdx.x; pr < G::WROWS; pr += NW * 64) {
+            for (int pr = t; pr < G::WROWS; pr += nt) {
                 const int w = pr - 1;
-                float v[8];
-                if (w < 0 || w >= KMER) {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) v[c] = 0.f;
-                } else {
+                float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+                if (w >= 0 && w < KMER) {
                     const int j = rev ? st.qoff + HK - w : st.qoff - HK + w;
                     if (j < 0 || j >= L) {  // outside the read: the reference zero-fills BEFORE bn0
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) v[c] = bn->zero[c];
+                        lo = make_float4(bn->zero[0], bn->zero[1], bn->zero[2], bn->zero[3]);
+                        hi = make_float4(bn->zero[4], bn->zero[5], bn->zero[6], bn->zero[7]);
                     } else {
                         int b = bases[bo + j];
                         uint32_t k = kin[bo + j];
                         if (rev) {
                             if (b < 4) b = 3 - b;
-                            k = (k >> 16) | (k << 16);
+                            k = (k >> 16) | (k << 16);  // own strand first: (ri, rp, fi, fp)
                         }
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = b == c ? bn->hot[c] : bn->zero[c];
-                        v[4] = bn->lut[0][k & 255];
-                        v[5] = bn->lut[1][(k >> 8) & 255];
-                        v[6] = bn->lut[2][(k >> 16) & 255];
-                        v[7] = bn->lut[3][k >> 24];
+                        lo = make_float4(b == 0 ? bn->hot[0] : bn->zero[0], b == 1 ? bn->hot[1] : bn->zero[1],
+                                         b == 2 ? bn->hot[2] : bn->zero[2], b == 3 ? bn->hot[3] : bn->zero[3]);
+                        hi = make_float4(bn->lut[0][k & 255], bn->lut[1][(k >> 8) & 255], bn->lut[2][(k >> 16) & 255],
+                                         bn->lut[3][k >> 24]);
                     }
                 }
-#pragma unroll
-                for (int c = 0; c < 8; ++c) bufB[pr * G::WRS + c] = v[c];
+                *reinterpret_cast<float4*>(bufB + pr * G::WRS) = lo;
+                *reinterpret_cast<float4*>(bufB + pr * G::WRS + 4) = hi;
             }
         } else {
             const float* __restrict__ src = windows + (size_t)s * (KMER * FEATS);
-            for (int i = threadIdx.x; i < G::WROWS * 8; i += NW * 64) {
+            for (int i = t; i < G::WROWS * 8; i += nt) {
                 const int pr = i >> 3, c = i & 7, w = pr - 1;
                 float v = 0.f;
                 if (w >= 0 && w < KMER) v = (src[w * 8 + c] - bn->mean[c]) / bn->sd[c] * bn->gamma[c] + bn->beta[c];
                 bufB[pr * G::WRS + c] = v;
             }
         }
+    };
+    // waves that do not take part in conv4 (8-wave build) prepare the next site's window meanwhile
+    constexpr int C4_WAVES = 4;
+    constexpr bool SPARE = NW > C4_WAVES;
+
+    if ((int)blockIdx.x < n_sites) build_window(blockIdx.x, threadIdx.x, NW * 64);
+    for (int s = blockIdx.x; s < n_sites; s += gridDim.x) {
+        if (STAMP) tprev = hm_stamp();
         HM_MARK(0)
-        __syncthreads();
+        __syncthreads();  // window of site s complete; previous conv4 done with bufA
         HM_MARK(1)
 
         // conv1: window (bufB) -> bufA
@@ -628,11 +631,19 @@ __global__ __launch_bounds__(NW * 64) void front_kernel(const Site* __restrict__
         HM_MARK(13)
         if (dbg && dbg_layer == 3 && s == 0) dump_lds<G::L3, 128, G::RS>(bufA, dbg);
 
-        // conv4: bufA -> act4[s] in HBM (hand-off to the tail kernel)
-        Conv<NW, 1, 128, 3, C4_CH, G::L4, G::RS, 0, 0, 2, (NW == 4 ? 2 : 3), 4>::run(
+        // conv4: bufA -> act4[s] in HBM (hand-off to the tail kernel), on the first 4 waves (one per SIMD,
+        // 3 tiles each); bufB is free now, so the next site's window is built alongside.
+        Conv<NW, 1, 128, 3, C4_CH, G::L4, G::RS, 0, 0, 2, 2, 6>::run(
             bufA, W.wfrag[3], EpiGlobal<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]}, [&](int k) __attribute__((always_inline)) { mk(14 + k); });
         HM_MARK(16)
-        __syncthreads();  // bufA/bufB are rewritten by the next site
+        const int sn = s + gridDim.x;
+        if (sn < n_sites) {
+            if (SPARE) {
+                if ((int)threadIdx.x >= C4_WAVES * 64) build_window(sn, threadIdx.x - C4_WAVES * 64, (NW - C4_WAVES) * 64);
+            } else {
+                build_window(sn, threadIdx.x, NW * 64);
+            }
+        }
         HM_MARK(17)
     }
 #undef HM_MARK
