@@ -318,13 +318,15 @@ __global__ __launch_bounds__(256) void window_kernel(const Site* __restrict__ si
 // The 4 waves of a workgroup tile the output as WM x WN blocks of (MTW x NTW) 16x16 tiles.
 
 template <int NW_, int S_, int CIN_, int KT_, int COUT_, int LOUT_, int IRS_, int ISS_, int ROW0_, int WM_, int WN_,
-          int BR_ = 2>
+          int BR_ = 2, int VR_ = 0>
 struct Conv {
     static constexpr int NW = NW_, S = S_, CIN = CIN_, KT = KT_, COUT = COUT_, LOUT = LOUT_, IRS = IRS_, ISS = ISS_;
     static constexpr int ROW0 = ROW0_, WM = WM_, WN = WN_;
     static constexpr int BR = BR_;  // B-fragment register ring: BR-1 k-groups in flight from L2
+    static constexpr int VR = VR_;  // ragged rows (M mod 16) computed on the VALU beside the MFMAs instead of
+                                    // padding one more 16-row MFMA tile with them
     static constexpr int M = S * LOUT;
-    static constexpr int MT = (M + 15) / 16;
+    static constexpr int MT = (M - VR + 15) / 16;
     static constexpr int NT = COUT / 16;
     static constexpr int MTW = (MT + WM - 1) / WM;
     static constexpr int NTW = NT / WN;
@@ -334,6 +336,7 @@ struct Conv {
     static_assert(CIN % 16 == 0 || 16 % CIN == 0, "a 16-wide k-group must not straddle taps unevenly");
     static_assert(IRS % 4 == 0 && ISS % 4 == 0, "A fragments are fetched with 16-byte LDS reads");
     static_assert(BR >= 2 && KG >= BR - 1 && KG >= 1, "bad pipeline depth");
+    static_assert(VR == 0 || (WM == 1 && S == 1 && (M - VR) % 16 == 0 && VR < 16), "VALU rows need a 1 x N wave grid");
 
     // LDS offset (floats) of the first element of k-group kg relative to physical row 2p+ROW0, channel 0
     static __device__ __forceinline__ int group_off(int kg) {
@@ -380,6 +383,19 @@ struct Conv {
             for (int i = 0; i < MTW; ++i) acc[i][j] = f32x4{bz.x, bz.y, bz.z, bz.w};
         }
 
+        // VALU rows: lane (li, lk) accumulates the partial dot product over its own 4 K elements per group for
+        // output channel nt*16 + li; the 4 lk lane-groups are summed once after the k-loop.
+        constexpr int VRN = VR > 0 ? VR : 1;
+        int roff[VRN];
+        float psum[VRN][NTW];
+        float4 ar[VRN];
+#pragma unroll
+        for (int r = 0; r < VRN; ++r) {
+            roff[r] = (2 * (MT * 16 + r) + ROW0) * IRS + lk_off;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) psum[r][j] = 0.f;
+        }
+
         const float4* wp = reinterpret_cast<const float4*>(wfrag) + (size_t)(wn * NTW) * KG * 64 + lane;
         float4 bq[BR][NTW];
         float4 a[2][MTW];
@@ -405,6 +421,11 @@ struct Conv {
 #pragma unroll
                 for (int i = 0; i < MTW; ++i) a[RA ^ 1][i] = *reinterpret_cast<const float4*>(gn + aoff[i]);
             }
+            if (VR > 0) {  // the VALU rows of THIS group: consumed after the MFMAs have been issued
+                const float* gc = in + group_off(kg);
+#pragma unroll
+                for (int r = 0; r < VRN; ++r) ar[r] = *reinterpret_cast<const float4*>(gc + roff[r]);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -416,6 +437,19 @@ struct Conv {
                         const float bv = s == 0 ? bq[RB][j].x : s == 1 ? bq[RB][j].y : s == 2 ? bq[RB][j].z : bq[RB][j].w;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
                     }
+            if (VR > 0) {
+#pragma unroll
+                for (int r = 0; r < VRN; ++r)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        float t = psum[r][j];
+                        t = fmaf(ar[r].x, bq[RB][j].x, t);
+                        t = fmaf(ar[r].y, bq[RB][j].y, t);
+                        t = fmaf(ar[r].z, bq[RB][j].z, t);
+                        t = fmaf(ar[r].w, bq[RB][j].w, t);
+                        psum[r][j] = t;
+                    }
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         mark(0);
@@ -444,6 +478,18 @@ struct Conv {
                 for (int j = 0; j < NTW; ++j) epi(m, (wn * NTW + j) * 16 + 4 * lk, acc[i][j]);
             }
         }
+        if (VR > 0) {
+#pragma unroll
+            for (int r = 0; r < VRN; ++r)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    float v = psum[r][j];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    const int col = (wn * NTW + j) * 16 + li;
+                    if (lk == (r & 3)) epi.store1(MT * 16 + r, col, v + epi.bias[col]);
+                }
+        }
     }
 };
 
@@ -469,6 +515,11 @@ struct EpiLds {
         *reinterpret_cast<float4*>(out + site * OSS + (p + 1) * ORS + col) =
             make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
     }
+    __device__ __forceinline__ void store1(int m, int col, float v) const {
+        const int site = OSS == 0 ? 0 : m / LOUT;
+        const int p = OSS == 0 ? m : m - site * LOUT;
+        out[site * OSS + (p + 1) * ORS + col] = fmaxf(v, 0.f);
+    }
 };
 
 // ReLU, result to global channels-last [m][COUT]
@@ -480,6 +531,7 @@ struct EpiGlobal {
         *reinterpret_cast<float4*>(out + (size_t)m * COUT + col) =
             make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
     }
+    __device__ __forceinline__ void store1(int m, int col, float v) const { out[(size_t)m * COUT + col] = fmaxf(v, 0.f); }
 };
 
 // zero the padding rows (physical rows 0 and LOUT+1) of S stacked sites
@@ -605,7 +657,7 @@ __global__ __launch_bounds__(NW * 64) void front_kernel(const Site* __restrict__
         HM_MARK(1)
 
         // conv1: window (bufB) -> bufA
-        Conv<NW, 1, 8, G::KT1, 128, G::L1, G::WRS, 0, 0, 1, NW>::run(
+        Conv<NW, 1, 8, G::KT1, 128, G::L1, G::WRS, 0, 0, 1, NW, 2, G::L1 % 16>::run(
             bufB, W.wfrag[0], EpiLds<G::L1, G::RS, 0>{bufA, W.bias[0]}, [&](int k) __attribute__((always_inline)) { mk(2 + k); });
         HM_MARK(4)
         zero_pad_rows<1, G::L1, 128, G::RS, 0>(bufA);
@@ -614,7 +666,7 @@ __global__ __launch_bounds__(NW * 64) void front_kernel(const Site* __restrict__
         if (dbg && dbg_layer == 1 && s == 0) dump_lds<G::L1, 128, G::RS>(bufA, dbg);
 
         // conv2: bufA -> bufB
-        Conv<NW, 1, 128, 3, 128, G::L2, G::RS, 0, 0, 1, NW>::run(
+        Conv<NW, 1, 128, 3, 128, G::L2, G::RS, 0, 0, 1, NW, 2, G::L2 % 16>::run(
             bufA, W.wfrag[1], EpiLds<G::L2, G::RS, 0>{bufB, W.bias[1]}, [&](int k) __attribute__((always_inline)) { mk(6 + k); });
         HM_MARK(8)
         zero_pad_rows<1, G::L2, 128, G::RS, 0>(bufB);
@@ -623,7 +675,7 @@ __global__ __launch_bounds__(NW * 64) void front_kernel(const Site* __restrict__
         if (dbg && dbg_layer == 2 && s == 0) dump_lds<G::L2, 128, G::RS>(bufB, dbg);
 
         // conv3: bufB -> bufA
-        Conv<NW, 1, 128, 3, 128, G::L3, G::RS, 0, 0, 1, NW, 3>::run(
+        Conv<NW, 1, 128, 3, 128, G::L3, G::RS, 0, 0, 1, NW, 3, G::L3 % 16>::run(
             bufB, W.wfrag[2], EpiLds<G::L3, G::RS, 0>{bufA, W.bias[2]}, [&](int k) __attribute__((always_inline)) { mk(10 + k); });
         HM_MARK(12)
         zero_pad_rows<1, G::L3, 128, G::RS, 0>(bufA);
