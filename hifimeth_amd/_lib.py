@@ -10,7 +10,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhifimeth_hip.so")
+LIB_PATH = os.environ.get("HM_LIB_PATH") or os.path.join(HERE, "libhifimeth_hip.so")  # HM_LIB_PATH: diagnostic builds
 CSRC = os.path.join(HERE, "csrc")
 WEIGHTS_DIR = os.path.join(HERE, "weights")
 

@@ -174,8 +174,8 @@ class MethylationCaller:
         return out[:n].reshape(-1, chans).copy()
 
     def stamps(self) -> list:
-        buf = (C.c_uint64 * 32)()
-        n = self._check(self._L.hm_get_stamps(self._h, buf, 32), "hm_get_stamps")
+        buf = (C.c_uint64 * 256)()
+        n = self._check(self._L.hm_get_stamps(self._h, buf, 256), "hm_get_stamps")
         return [int(buf[i]) for i in range(n)]
 
     def timing(self, reset: bool = False) -> dict:

@@ -225,8 +225,8 @@ void accumulate_stamps(hm_engine* e) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(h.data(), e->d_stamps.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(e->d_stamps.p, 0, n * sizeof(unsigned long long)));
-    e->stamp_sum.resize((size_t)ns, 0);
-    for (size_t i = 0; i < n; ++i) e->stamp_sum[i % ns] += h[i];
+    e->stamp_sum.resize((size_t)ns * 8, 0);
+    for (size_t i = 0; i < n; ++i) e->stamp_sum[i % ((size_t)ns * 8)] += h[i];  // [wave in workgroup][slot]
 }
 
 // front + tail over `n` sites of one context, in sub-batches that bound the act4 hand-off buffer
@@ -343,7 +343,7 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
                 const size_t bytes = (size_t)e->num_cu * 8 * front_stamp_slots() * sizeof(unsigned long long);
                 e->d_stamps.reserve(bytes);
                 HIP_TRY(hipMemset(e->d_stamps.p, 0, bytes));
-                e->stamp_sum.assign((size_t)front_stamp_slots(), 0);
+                e->stamp_sum.assign((size_t)front_stamp_slots() * 8, 0);
             } catch (const HipErr& h) {
                 return fail_hip(e, h);
             }

@@ -396,10 +396,22 @@ struct Conv {
             for (int j = 0; j < NTW; ++j) psum[r][j] = 0.f;
         }
 
+        float bcol[NTW];  // bias of this lane's VALU-row output channel, fetched up front
+        if (VR > 0) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) bcol[j] = epi.bias[(wn * NTW + j) * 16 + li];
+        }
+
         const float4* wp = reinterpret_cast<const float4*>(wfrag) + (size_t)(wn * NTW) * KG * 64 + lane;
         float4 bq[BR][NTW];
         float4 a[2][MTW];
         // prologue: BR-1 k-groups of B and one k-group of A in flight
+#if defined(HM_ABL_NOB) || defined(HM_ABL_NOA)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bq[BR - 1][j] = wp[(size_t)(j * KG) * 64];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) a[1][i] = *reinterpret_cast<const float4*>(in + aoff[i]);
+#endif
 #pragma unroll
         for (int r = 0; r < BR - 1; ++r)
 #pragma unroll
@@ -412,21 +424,30 @@ struct Conv {
         auto group = [&](auto rb_tag, auto ra_tag, const int kg) __attribute__((always_inline)) {
             constexpr int RB = decltype(rb_tag)::value;
             constexpr int RA = decltype(ra_tag)::value;
-            if (kg + BR - 1 < KG) {
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) bq[(RB + BR - 1) % BR][j] = wp[(size_t)(j * KG + kg + BR - 1) * 64];
-            }
-            if (kg + 1 < KG) {
-                const float* gn = in + group_off(kg + 1);
-#pragma unroll
-                for (int i = 0; i < MTW; ++i) a[RA ^ 1][i] = *reinterpret_cast<const float4*>(gn + aoff[i]);
-            }
-            if (VR > 0) {  // the VALU rows of THIS group: consumed after the MFMAs have been issued
+            // loads are unconditional (the last groups re-fetch the final group) so that the body stays one
+            // basic block = one scheduling region
+            if (VR > 0) {  // the VALU rows of THIS group
                 const float* gc = in + group_off(kg);
 #pragma unroll
                 for (int r = 0; r < VRN; ++r) ar[r] = *reinterpret_cast<const float4*>(gc + roff[r]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+#ifndef HM_ABL_NOB
+            {
+                const int kb = kg + BR - 1 < KG ? kg + BR - 1 : KG - 1;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) bq[(RB + BR - 1) % BR][j] = wp[(size_t)(j * KG + kb) * 64];
+            }
+#endif
+#ifndef HM_ABL_NOA
+            {
+                const float* gn = in + group_off(kg + 1 < KG ? kg + 1 : KG - 1);
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) a[RA ^ 1][i] = *reinterpret_cast<const float4*>(gn + aoff[i]);
+            }
+#endif
+#ifndef HM_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);  // loads first, then the MFMA block (measured faster than interleaving)
+#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -450,6 +471,40 @@ struct Conv {
                         psum[r][j] = t;
                     }
             }
+#ifdef HM_INTERLEAVE
+            // Issue order inside the group: every non-MFMA instruction goes into the shadow of an MFMA (an MFMA
+            // occupies the matrix pipe for 32 cycles but the issue port only briefly), instead of a block of
+            // loads in front of a block of MFMAs: VALU-row reads first (their FMAs come last), then the B and A
+            // prefetches, then the FMAs.
+            constexpr int NM = 4 * MTW * NTW;
+            constexpr int NVR = VR > 0 ? VR : 0;
+            constexpr int NSLOT = NVR + NTW + MTW + NVR * NTW;  // interleave points
+            constexpr int MPS = NM / NSLOT > 0 ? NM / NSLOT : 1;  // MFMAs per interleave point
+#pragma unroll
+            for (int t = 0; t < NVR; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MPS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MPS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < MTW; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MPS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NVR * NTW; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MPS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);  // whatever MFMAs are left
+#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         mark(0);
@@ -487,7 +542,7 @@ struct Conv {
                     v += __shfl_xor(v, 16, 64);
                     v += __shfl_xor(v, 32, 64);
                     const int col = (wn * NTW + j) * 16 + li;
-                    if (lk == (r & 3)) epi.store1(MT * 16 + r, col, v + epi.bias[col]);
+                    if (lk == (r & 3)) epi.store1(MT * 16 + r, col, v + bcol[j]);
                 }
         }
     }
@@ -649,6 +704,10 @@ __global__ __launch_bounds__(NW * 64) void front_kernel(const Site* __restrict__
     constexpr int C4_WAVES = 4;
     constexpr bool SPARE = NW > C4_WAVES;
 
+#ifdef HM_EXP_PRIO
+    // static priority for the younger half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (NW == 8 && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
     if ((int)blockIdx.x < n_sites) build_window(blockIdx.x, threadIdx.x, NW * 64);
     for (int s = blockIdx.x; s < n_sites; s += gridDim.x) {
         if (STAMP) tprev = hm_stamp();

@@ -13,7 +13,14 @@ with MethylationCaller(timing=True) as mc:
     mc.set_option("stamps", 1)
     mc.run(); mc.sync()
     st = mc.stamps()
+    ns = len(st) // 8
+    per_wave = [st[w * ns:(w + 1) * ns] for w in range(8)]
+    nsite_wg = mc.num_sites(3) / 256
     tot = sum(st)
-    for n, v in zip(names, st):
-        print(f"{n:18s} {100.0 * v / tot:6.2f} %   {v / (256 * 8) / (mc.num_sites(3) / 256):9.0f} cyc/site")
-    print("sites", mc.num_sites(3), "cycles/site/wave", tot / (256 * 8) / (mc.num_sites(3) / 256))
+    print(f"{'phase':18s} {'all %':>7s} {'cyc/site':>9s} | waves 0-3 | waves 4-7")
+    for i, n in enumerate(names):
+        v = sum(pw[i] for pw in per_wave)
+        lo = sum(pw[i] for pw in per_wave[:4]) / 4 / 256 / nsite_wg
+        hi = sum(pw[i] for pw in per_wave[4:]) / 4 / 256 / nsite_wg
+        print(f"{n:18s} {100.0 * v / tot:6.2f}  {v / (256 * 8) / nsite_wg:9.0f} | {lo:9.0f} | {hi:9.0f}")
+    print("sites", mc.num_sites(3), "cycles/site/wave", tot / (256 * 8) / nsite_wg)
