@@ -50,6 +50,13 @@ struct BnTables {
     float raw_lut[256];  // codev1_decode(code) / 952 (fp32 divide, eval_kmer_features.cpp:46-60)
 };
 
+// the same tables split into fp16 hi | lo << 16 for the split-half (f16x3) front kernel
+struct BnTablesH {
+    uint32_t hot[4];
+    uint32_t zero[8];
+    uint32_t lut[4][256];
+};
+
 // per-context device weights: MFMA-fragment-packed conv/fc weights + biases
 struct CtxWeights {
     const float* wfrag[9];   // conv1..conv8, fc1 : [n-tile][k-group][lane][4]
@@ -57,6 +64,8 @@ struct CtxWeights {
     const float* fc2_w;      // [2][256]
     const float* fc2_b;      // [2]
     const BnTables* bn;
+    const uint16_t* wfrag_h[4];  // conv1..conv4 as fp16 hi/lo fragments: [n-tile][k-block of 32][plane][lane][8]
+    const BnTablesH* bn_h;
     int k1;
 };
 

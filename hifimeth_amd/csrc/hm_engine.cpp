@@ -97,6 +97,7 @@ struct hm_engine {
     int min_read_size = 1000;  // mod_options.cpp:10
     int64_t sub_batch = 65536;
     int front_waves = 8;
+    int precision = 0;  // 0 = fp32 MFMA (exact), 1 = split-half f16x3 MFMA with fp32 accumulate
     bool stamps_on = false;
     std::vector<unsigned long long> stamp_sum;
     bool timing = false;
@@ -203,6 +204,8 @@ void upload_model(hm_engine* e, int ctx, const HostModel& hmw) {
     dm.w.fc2_w = base + pk.fc2_w_off;
     dm.w.fc2_b = base + pk.fc2_b_off;
     dm.w.bn = reinterpret_cast<const BnTables*>(base + pk.bn_off);
+    for (int i = 0; i < 4; ++i) dm.w.wfrag_h[i] = reinterpret_cast<const uint16_t*>(base + pk.wfrag_h_off[i]);
+    dm.w.bn_h = reinterpret_cast<const BnTablesH*>(base + pk.bn_h_off);
     dm.w.k1 = hmw.k1;
     dm.k1 = hmw.k1;
     dm.loaded = true;
@@ -240,10 +243,14 @@ void run_cnn(hm_engine* e, int ctx, const Site* sites, const float* windows, int
         const float* w_off = windows ? windows + (size_t)off * KMER * FEATS : nullptr;
         {
             Span sp(e, K_FRONT0 + ctx, m);
-            launch_front(e->stream, dm.k1, s_off, m, e->d_reads.as<ReadDesc>(), e->d_bases.as<uint8_t>(),
-                         e->d_kin.as<uint32_t>(), w_off, dm.w, e->d_act4.as<float>(), e->num_cu, dbg, dbg_layer,
-                         e->front_waves, e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr);
-            if (e->stamps_on) accumulate_stamps(e);
+            if (e->precision == 1)
+                launch_front_h(e->stream, dm.k1, s_off, m, e->d_reads.as<ReadDesc>(), e->d_bases.as<uint8_t>(),
+                               e->d_kin.as<uint32_t>(), w_off, dm.w, e->d_act4.as<float>(), e->num_cu, dbg, dbg_layer);
+            else
+                launch_front(e->stream, dm.k1, s_off, m, e->d_reads.as<ReadDesc>(), e->d_bases.as<uint8_t>(),
+                             e->d_kin.as<uint32_t>(), w_off, dm.w, e->d_act4.as<float>(), e->num_cu, dbg, dbg_layer,
+                             e->front_waves, e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr);
+            if (e->stamps_on && e->precision == 0) accumulate_stamps(e);
             sp.end();
         }
         {
@@ -336,7 +343,10 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
     const std::string k(key);
     if (k == "min_read_size") e->min_read_size = (int)value;
     else if (k == "timing") e->timing = value != 0;
-    else if (k == "stamps") {
+    else if (k == "precision") {
+        if (value != 0 && value != 1) return fail(e, HM_EINVAL, "precision must be 0 (fp32) or 1 (f16x3 split)");
+        e->precision = (int)value;
+    } else if (k == "stamps") {
         e->stamps_on = value != 0;
         if (e->stamps_on) {
             try {

@@ -1,0 +1,343 @@
+// hm_front_h.hip -- split-half ("f16x3") variant of the front kernel (window + bn0 + conv1..conv4).
+//
+// Every fp32 value x is carried as two halves  x = hi + lo  (hi = fp16(x), lo = fp16(x - hi), ~22 significant
+// bits) and every product as three fp16 MFMAs with fp32 accumulation:
+//     w*x ~= w_hi*x_hi + w_hi*x_lo + w_lo*x_hi          (v_mfma_f32_16x16x32_f16, 16x the fp32 MFMA rate)
+// The dropped w_lo*x_lo term is ~2^-22 relative.  Accumulators, biases and the ReLU stay fp32; the outputs of a
+// layer are split again when they are written to LDS.  Same algorithm and layouts as hm_kernels.hip otherwise:
+// one site per workgroup pass, activations channels-last in LDS (now as an fp16 hi plane and an fp16 lo plane,
+// 4 bytes per element as before), weights as the MFMA A operand so that a lane owns 4 consecutive channels.
+// Reference for what is computed: training/model_cnn.py:8-85 / models/*.onnx (mod_main.cpp:32-98).
+#include <type_traits>
+#include <utility>
+
+#include "hm_kernels.h"
+
+namespace hm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half_t;
+
+__device__ __forceinline__ void split4(const f32x4& v, half4& hi, half4& lo) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float x = fmaxf(v[r], 0.f);  // ReLU
+        const half_t h = (half_t)x;
+        hi[r] = h;
+        lo[r] = (half_t)(x - (float)h);
+    }
+}
+
+// K is processed in blocks of 32 (one MFMA).  Lane (li = l&15, lk = l>>4) owns 8 consecutive K elements:
+//   CIN >= 32 : channels c0 + 8*lk .. +7 of tap (32*kb)/CIN          (a block never straddles taps)
+//   CIN == 8  : all 8 channels of tap 4*kb + lk
+template <int NW_, int CIN_, int KT_, int COUT_, int LOUT_, int IRS_, int WM_, int WN_, int BR_ = 2>
+struct ConvH {
+    static constexpr int NW = NW_, CIN = CIN_, KT = KT_, COUT = COUT_, LOUT = LOUT_, IRS = IRS_, WM = WM_, WN = WN_, BR = BR_;
+    static constexpr int M = LOUT;
+    static constexpr int MT = (M + 15) / 16;
+    static constexpr int NT = COUT / 16;
+    static constexpr int MTW = (MT + WM - 1) / WM;
+    static constexpr int NTW = NT / WN;
+    static constexpr int K = KT * CIN;
+    static constexpr int KB = K / 32;
+    static_assert(K % 32 == 0 && NT % WN == 0 && WM * WN <= NW && (CIN % 32 == 0 || CIN == 8), "bad conv geometry");
+    static_assert(IRS % 8 == 0 && BR >= 2 && KB >= BR - 1, "bad layout / pipeline depth");
+
+    static __device__ __forceinline__ int block_off(int kb) {
+        if (CIN == 8) return 4 * kb * IRS;
+        const int kk = kb * 32;
+        const int tap = kk / CIN;
+        return tap * IRS + (kk - tap * CIN);
+    }
+
+    template <class Epi>
+    static __device__ __forceinline__ void run(const half_t* __restrict__ in_hi, const half_t* __restrict__ in_lo,
+                                               const half_t* __restrict__ wfrag, Epi epi) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // keep this layer's address arithmetic out of the persistent site loop
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        if (WM * WN < NW && wave >= WM * WN) return;
+        const int wm = WM == 1 ? 0 : wave / WN, wn = WM == 1 ? wave : wave % WN;
+        const int li = lane & 15, lk = lane >> 4;
+        const int lk_off = CIN == 8 ? lk * IRS : 8 * lk;
+
+        int aoff[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            int m = (wm * MTW + i) * 16 + li;
+            m = m < M ? m : M - 1;
+            aoff[i] = 2 * m * IRS + lk_off;
+        }
+        f32x4 acc[MTW][NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const float4 bz = *reinterpret_cast<const float4*>(epi.bias + (wn * NTW + j) * 16 + 4 * lk);
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) acc[i][j] = f32x4{bz.x, bz.y, bz.z, bz.w};
+        }
+
+        // weights: [n-tile][k-block][plane hi/lo][lane] half8
+        const half8* wp = reinterpret_cast<const half8*>(wfrag) + (size_t)(wn * NTW) * KB * 128 + lane;
+        half8 wq[BR][NTW][2];
+        half8 x[2][MTW][2];
+#pragma unroll
+        for (int r = 0; r < BR - 1; ++r)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                wq[r][j][0] = wp[(size_t)(j * KB + r) * 128];
+                wq[r][j][1] = wp[(size_t)(j * KB + r) * 128 + 64];
+            }
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            x[0][i][0] = *reinterpret_cast<const half8*>(in_hi + aoff[i]);
+            x[0][i][1] = *reinterpret_cast<const half8*>(in_lo + aoff[i]);
+        }
+
+        auto block = [&](auto rb_tag, auto ra_tag, const int kb) __attribute__((always_inline)) {
+            constexpr int RB = decltype(rb_tag)::value;
+            constexpr int RA = decltype(ra_tag)::value;
+            {
+                const int kw = kb + BR - 1 < KB ? kb + BR - 1 : KB - 1;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    wq[(RB + BR - 1) % BR][j][0] = wp[(size_t)(j * KB + kw) * 128];
+                    wq[(RB + BR - 1) % BR][j][1] = wp[(size_t)(j * KB + kw) * 128 + 64];
+                }
+            }
+            {
+                const int bo = block_off(kb + 1 < KB ? kb + 1 : KB - 1);
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) {
+                    x[RA ^ 1][i][0] = *reinterpret_cast<const half8*>(in_hi + bo + aoff[i]);
+                    x[RA ^ 1][i][1] = *reinterpret_cast<const half8*>(in_lo + bo + aoff[i]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the three partial products, outermost so that an accumulator is revisited only after
+            // MTW*NTW other MFMAs (no back-to-back dependent MFMAs)
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[RB][j][pr == 2 ? 1 : 0], x[RA][i][pr == 1 ? 1 : 0],
+                                                                           acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        constexpr int UN = BR % 2 == 0 ? BR : 2 * BR;
+        int kb = 0;
+#pragma nounroll
+        for (; kb + UN <= KB; kb += UN) {
+            [&]<int... R>(std::integer_sequence<int, R...>) __attribute__((always_inline)) {
+                (block(std::integral_constant<int, R % BR>{}, std::integral_constant<int, R % 2>{}, kb + R), ...);
+            }(std::make_integer_sequence<int, UN>{});
+        }
+        [&]<int... R>(std::integer_sequence<int, R...>) __attribute__((always_inline)) {
+            ((R < KB % UN ? block(std::integral_constant<int, R % BR>{}, std::integral_constant<int, R % 2>{}, KB - KB % UN + R)
+                          : (void)0), ...);
+        }(std::make_integer_sequence<int, UN>{});
+
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            const int m = (wm * MTW + i) * 16 + li;
+            const bool full = WM == 1 ? (i + 1) * 16 <= M : false;
+            if (full || m < M) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) epi(m, (wn * NTW + j) * 16 + 4 * lk, acc[i][j]);
+            }
+        }
+    }
+};
+
+// ReLU + split; 4 consecutive channels of position m -> the hi and lo planes (physical row m+1)
+template <int ORS>
+struct EpiPlanes {
+    half_t* hi;
+    half_t* lo;
+    const float* __restrict__ bias;
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        half4 h, l;
+        split4(acc, h, l);
+        *reinterpret_cast<half4*>(hi + (m + 1) * ORS + col) = h;
+        *reinterpret_cast<half4*>(lo + (m + 1) * ORS + col) = l;
+    }
+};
+
+template <int COUT>
+struct EpiGlobalF {
+    float* __restrict__ out;
+    const float* __restrict__ bias;
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        *reinterpret_cast<float4*>(out + (size_t)m * COUT + col) =
+            make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+    }
+};
+
+template <int K1>
+struct GeoH {
+    static constexpr int L1 = (KMER + 2 - K1) / 2 + 1;
+    static constexpr int L2 = (L1 - 1) / 2 + 1;
+    static constexpr int L3 = (L2 - 1) / 2 + 1;
+    static constexpr int L4 = (L3 - 1) / 2 + 1;
+    static constexpr int KT1 = (K1 * FEATS + 31) / 32 * 4;  // taps incl. zero-weight K padding: 12 / 16
+    static constexpr int WRS = 8;                            // window row = 8 halves = 16 bytes, no padding needed
+    static constexpr int WROWS = 2 * (L1 - 1) + KT1;
+    static constexpr int RS = 136;                           // 128 channels + 8 halves: 272-byte rows
+    // sizes in halves of ONE plane
+    static constexpr int A1 = (L1 + 2) * RS, A2 = (L2 + 2) * RS, A3 = (L3 + 2) * RS, WIN = WROWS * WRS;
+    static constexpr int PA = A1 > A3 ? A1 : A3;  // plane size in buffer A
+    static constexpr int PB = WIN > A2 ? WIN : A2;
+    static constexpr int LDS_HALVES = 2 * PA + 2 * PB;
+    static_assert(LDS_HALVES * 2 <= 163840, "LDS plan");
+};
+
+template <int C>
+__device__ __forceinline__ void zero_rows_h(half_t* hi, half_t* lo, int row0, int row1, int rs) {
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        const int which = i / C, c = i - which * C;
+        const int o = (which ? row1 : row0) * rs + c;
+        hi[o] = (half_t)0.f;
+        lo[o] = (half_t)0.f;
+    }
+}
+
+template <int L, int C, int RS>
+__device__ __forceinline__ void dump_planes(const half_t* hi, const half_t* lo, float* __restrict__ dbg) {
+    for (int i = threadIdx.x; i < L * C; i += blockDim.x) {
+        const int o = (i / C + 1) * RS + (i % C);
+        dbg[i] = (float)hi[o] + (float)lo[o];
+    }
+}
+
+template <int K1, bool RAW>
+__global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ sites, int n_sites,
+                                                       const ReadDesc* __restrict__ reads,
+                                                       const uint8_t* __restrict__ bases,
+                                                       const uint32_t* __restrict__ kin,
+                                                       const float* __restrict__ windows, CtxWeights W,
+                                                       float* __restrict__ act4, float* __restrict__ dbg, int dbg_layer) {
+    using G = GeoH<K1>;
+    constexpr int NW = 8;
+    __shared__ __attribute__((aligned(16))) half_t smem[G::LDS_HALVES];
+    half_t* a_hi = smem;
+    half_t* a_lo = smem + G::PA;
+    half_t* b_hi = smem + 2 * G::PA;
+    half_t* b_lo = smem + 2 * G::PA + G::PB;
+    const BnTables* __restrict__ bn = W.bn;
+    const BnTablesH* __restrict__ bh = W.bn_h;
+
+    // window rows of site s -> planes B.  One thread per physical row: 8 halves (16 bytes) per plane.
+    auto build_window = [&](const int s, const int t, const int nt) __attribute__((always_inline)) {
+        int L = 0, qoff = 0, rev = 0;
+        int64_t bo = 0;
+        const float* src = nullptr;
+        if (RAW) {
+            const Site st = sites[s];
+            L = reads[st.read_idx].len;
+            bo = reads[st.read_idx].base_off;
+            qoff = st.qoff;
+            rev = bases[bo + qoff] == 2;
+        } else {
+            src = windows + (size_t)s * (KMER * FEATS);
+        }
+        for (int pr = t; pr < G::WROWS; pr += nt) {
+            const int w = pr - 1;
+            uint32_t v[8];  // (hi | lo << 16) per channel
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = 0u;
+            if (w >= 0 && w < KMER) {
+                if (RAW) {
+                    const int j = rev ? qoff + HK - w : qoff - HK + w;
+                    if (j < 0 || j >= L) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] = bh->zero[c];
+                    } else {
+                        int b = bases[bo + j];
+                        uint32_t k = kin[bo + j];
+                        if (rev) {
+                            if (b < 4) b = 3 - b;
+                            k = (k >> 16) | (k << 16);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = b == c ? bh->hot[c] : bh->zero[c];
+                        v[4] = bh->lut[0][k & 255];
+                        v[5] = bh->lut[1][(k >> 8) & 255];
+                        v[6] = bh->lut[2][(k >> 16) & 255];
+                        v[7] = bh->lut[3][k >> 24];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float x = (src[w * 8 + c] - bn->mean[c]) / bn->sd[c] * bn->gamma[c] + bn->beta[c];
+                        const half_t h = (half_t)x;
+                        const half_t l = (half_t)(x - (float)h);
+                        v[c] = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
+                    }
+                }
+            }
+            uint4 ph, pl;
+            ph.x = (v[0] & 0xffffu) | (v[1] << 16);
+            ph.y = (v[2] & 0xffffu) | (v[3] << 16);
+            ph.z = (v[4] & 0xffffu) | (v[5] << 16);
+            ph.w = (v[6] & 0xffffu) | (v[7] << 16);
+            pl.x = (v[0] >> 16) | (v[1] & 0xffff0000u);
+            pl.y = (v[2] >> 16) | (v[3] & 0xffff0000u);
+            pl.z = (v[4] >> 16) | (v[5] & 0xffff0000u);
+            pl.w = (v[6] >> 16) | (v[7] & 0xffff0000u);
+            *reinterpret_cast<uint4*>(b_hi + pr * G::WRS) = ph;
+            *reinterpret_cast<uint4*>(b_lo + pr * G::WRS) = pl;
+        }
+    };
+
+    if ((int)blockIdx.x < n_sites) build_window(blockIdx.x, threadIdx.x, NW * 64);
+    for (int s = blockIdx.x; s < n_sites; s += gridDim.x) {
+        __syncthreads();  // window of site s complete; previous conv4 done with planes A
+
+        // conv1: window (planes B) -> planes A
+        ConvH<NW, 8, G::KT1, 128, G::L1, G::WRS, 2, 4, 2>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[0]),
+                                                             EpiPlanes<G::RS>{a_hi, a_lo, W.bias[0]});
+        zero_rows_h<128>(a_hi, a_lo, 0, G::L1 + 1, G::RS);
+        __syncthreads();
+        if (dbg && dbg_layer == 1 && s == 0) dump_planes<G::L1, 128, G::RS>(a_hi, a_lo, dbg);
+
+        // conv2: planes A -> planes B
+        ConvH<NW, 128, 3, 128, G::L2, G::RS, 2, 4, 2>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]),
+                                                           EpiPlanes<G::RS>{b_hi, b_lo, W.bias[1]});
+        zero_rows_h<128>(b_hi, b_lo, 0, G::L2 + 1, G::RS);
+        __syncthreads();
+        if (dbg && dbg_layer == 2 && s == 0) dump_planes<G::L2, 128, G::RS>(b_hi, b_lo, dbg);
+
+        // conv3: planes B -> planes A
+        ConvH<NW, 128, 3, 128, G::L3, G::RS, 2, 4, 3>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
+                                                           EpiPlanes<G::RS>{a_hi, a_lo, W.bias[2]});
+        zero_rows_h<128>(a_hi, a_lo, 0, G::L3 + 1, G::RS);
+        __syncthreads();
+        if (dbg && dbg_layer == 3 && s == 0) dump_planes<G::L3, 128, G::RS>(a_hi, a_lo, dbg);
+
+        // conv4: planes A -> act4[s] (fp32, hand-off to the fp32 tail kernel) on the first 4 waves;
+        // the other 4 build the next site's window in planes B meanwhile
+        ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 2, 2, 4>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]),
+                                                            EpiGlobalF<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]});
+        const int sn = s + gridDim.x;
+        if (sn < n_sites && (int)threadIdx.x >= 256) build_window(sn, threadIdx.x - 256, 256);
+    }
+}
+
+void launch_front_h(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
+                    const uint32_t* kin, const float* windows, const CtxWeights& w, float* act4, int grid, float* dbg,
+                    int dbg_layer) {
+    if (n <= 0) return;
+    const dim3 g(min(n, grid)), b(512);
+    const bool raw = windows == nullptr;
+#define HM_FRONT_H(K1, RAW) \
+    hipLaunchKernelGGL((front_kernel_h<K1, RAW>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer)
+    if (k1 == 11) { if (raw) HM_FRONT_H(11, true); else HM_FRONT_H(11, false); }
+    else { if (raw) HM_FRONT_H(13, true); else HM_FRONT_H(13, false); }
+#undef HM_FRONT_H
+}
+
+}  // namespace hm

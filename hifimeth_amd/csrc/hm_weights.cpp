@@ -480,6 +480,49 @@ PackedModel pack_model(const HostModel& m) {
     const size_t nf = (sizeof(BnTables) + 3) / 4;
     b.resize(b.size() + nf);
     memcpy(b.data() + pk.bn_off, &bn, sizeof bn);
+
+    // ---- split-half (f16x3) data: x = hi + lo with hi = fp16(x), lo = fp16(x - hi) ----------------------
+    auto split = [](float x) -> uint32_t {
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        uint16_t hb, lb;
+        memcpy(&hb, &h, 2);
+        memcpy(&lb, &l, 2);
+        return (uint32_t)hb | ((uint32_t)lb << 16);
+    };
+    for (int i = 0; i < 4; ++i) {  // conv1..conv4: [n-tile][k-block of 32][plane][lane][8 halves]
+        const int cin = kChannels[i], cout = kChannels[i + 1], k = m.kernel[i];
+        const int K_real = k * cin, KB = (K_real + 31) / 32, NT = cout / 16;
+        align_blob(b);
+        pk.wfrag_h_off[i] = b.size();
+        std::vector<uint16_t> hw((size_t)NT * KB * 2 * 64 * 8);
+        const std::vector<float>& w = m.conv_w[i];
+        size_t o = 0;
+        for (int nt = 0; nt < NT; ++nt)
+            for (int kb = 0; kb < KB; ++kb)
+                for (int plane = 0; plane < 2; ++plane)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int kk = kb * 32 + 8 * (lane >> 4) + j;  // kk = tap*CIN + c
+                            const int co = nt * 16 + (lane & 15);
+                            uint32_t hl = 0;
+                            if (kk < K_real) hl = split(w[((size_t)co * cin + kk % cin) * k + kk / cin]);
+                            hw[o++] = (uint16_t)(plane ? hl >> 16 : hl & 0xffffu);
+                        }
+        const size_t nfl = (hw.size() * 2 + 3) / 4;
+        b.resize(b.size() + nfl);
+        memcpy(b.data() + pk.wfrag_h_off[i], hw.data(), hw.size() * 2);
+    }
+    BnTablesH bh;
+    for (int c = 0; c < 8; ++c) bh.zero[c] = split(bn.zero[c]);
+    for (int c = 0; c < 4; ++c) {
+        bh.hot[c] = split(bn.hot[c]);
+        for (int t = 0; t < 256; ++t) bh.lut[c][t] = split(bn.lut[c][t]);
+    }
+    align_blob(b);
+    pk.bn_h_off = b.size();
+    b.resize(b.size() + (sizeof(BnTablesH) + 3) / 4);
+    memcpy(b.data() + pk.bn_h_off, &bh, sizeof bh);
     return pk;
 }
 

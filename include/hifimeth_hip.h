@@ -74,7 +74,8 @@ int hm_create(hm_engine_t** out, const char* model_dir, int ctx_mask, int device
 void hm_destroy(hm_engine_t* e);
 const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a failed hm_create */
 /* options: "min_read_size" (-l, default 1000), "timing" (0/1), "sub_batch_sites" (front/tail
- * launch granularity, default 65536), "front_waves" (4 or 8 waves per front workgroup), "stamps" (diagnostic) */
+ * launch granularity, default 65536), "front_waves" (4 or 8 waves per front workgroup), "precision" (0 = fp32 MFMA, exact;
+ * 1 = split-half fp16x3 MFMA with fp32 accumulate for conv1..conv4), "stamps" (diagnostic) */
 int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
 
 /* ---- staging: the EvalKmerFeaturesGenerator::init seam ----------------------------------- */

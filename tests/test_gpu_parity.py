@@ -235,6 +235,30 @@ def test_front_wave_configs(mc, oracle, oracle_models, waves):
         mc.set_option("front_waves", 4)
 
 
+def test_split_half_precision_mode(mc, oracle, oracle_models):
+    """Option precision=1: conv1..conv4 on fp16 MFMA with hi+lo split operands and fp32 accumulation.
+    Must hold the SAME bar as the fp32 path: |dp| <= 1e-4, ML within 1 LSB."""
+    reads = _mixed_reads()[:8] + synth_reads(2, seed=12, median_len=4000, sigma=0.1, frac_short=0, frac_missing=0)
+    z = np.load(os.path.join(GOLDEN, "cnn_CpG.npz"))
+    om = oracle.Model(os.path.join(WEIGHTS, "CpG.hmw"))
+    mc.set_option("precision", 1)
+    try:
+        for layer in (1, 2, 3, 4):
+            want = om.layer(z["windows"][5], layer)
+            got = mc.debug_layer(0, z["windows"][5], layer)
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), layer
+        lg, p, ml = mc.cnn_logits(0, z["windows"])
+        pr, mlr = oracle.softmax(z["logits"])
+        assert np.abs(p - pr).max() <= DP_TOL
+        calls = mc.call(reads)
+        n, nml, worst = _check_calls(calls, reads, oracle, oracle_models, 7)
+        assert n > 3000
+        print(f"f16x3: {n} sites, max|dp|={worst:.2e}, ML bytes differing by 1: {nml}")
+    finally:
+        mc.set_option("precision", 0)
+
+
 def test_empty_and_skipped(mc):
     mc.clear()
     mc.upload()
