@@ -28,6 +28,7 @@ MAC_FRONT = {0: 197 * 128 * 88 + 99 * 128 * 384 + 50 * 128 * 384 + 25 * 96 * 384
              1: 197 * 128 * 88 + 99 * 128 * 384 + 50 * 128 * 384 + 25 * 96 * 384,
              2: 196 * 128 * 104 + 98 * 128 * 384 + 49 * 128 * 384 + 25 * 96 * 384}
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
+PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (2:1-sparsity figures excluded)
 
 
 def host_cores():
@@ -45,8 +46,9 @@ def host_cores():
     return n
 
 
-def cpu_baseline(reads, budget_s=15.0):
-    """The CPU oracle (port of the reference path) timed on this node's host cores, bounded sample."""
+def cpu_baseline(reads, gpu_calls=None, budget_s=15.0):
+    """The CPU oracle (port of the reference path) timed on this node's host cores, bounded sample.
+    The oracle's results for that sample double as an in-run parity check of the GPU calls."""
     from oracle import hm_oracle as O
     O.build()
     cores = host_cores()
@@ -54,17 +56,53 @@ def cpu_baseline(reads, budget_s=15.0):
     t0 = time.perf_counter()
     sites = 0
     nreads = 0
-    for rd in reads:
+    worst, nml, ncheck = 0.0, 0, 0
+    for rid, rd in enumerate(reads):
         if not rd.has_kinetics() or rd.l_qseq < 1000:
             continue
-        sites += len(O.call_read(models, 7, rd, nthreads=cores)["qoff"])
+        t1 = time.perf_counter()
+        want = O.call_read(models, 7, rd, nthreads=cores)
+        spent = time.perf_counter() - t1
+        sites += len(want["qoff"])
         nreads += 1
+        if gpu_calls is not None:  # untimed: compare with the GPU's calls for the same read
+            t0 += 0.0
+            tchk = time.perf_counter()
+            got = gpu_calls[gpu_calls["read_id"] == rid]
+            order = np.lexsort((want["qoff"], want["strand"]))
+            assert len(got) == len(order) and np.array_equal(got["qoff"], want["qoff"][order]), "site lists differ"
+            worst = max(worst, float(np.abs(got["p"] - want["p"][order]).max(initial=0)))
+            nml += int((got["scaled_prob"] != want["ml"][order]).sum())
+            ncheck += len(got)
+            t0 += time.perf_counter() - tchk  # keep the comparison out of the timed span
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": sites / dt, "unit": "sites/s", "cores": cores, "kind": "port",
-            "sample": f"first {nreads} reads of the rank-0 batch ({sites} sites, all contexts), "
-                      f"oracle/hm_oracle.c fp32, OpenMP over sites, {dt:.1f} s"}
+    out = {"value": sites / dt, "unit": "sites/s", "cores": cores, "kind": "port",
+           "sample": f"first {nreads} reads of the rank-0 batch ({sites} sites, all contexts), "
+                     f"oracle/hm_oracle.c fp32, OpenMP over sites, {dt:.1f} s"}
+    parity = None
+    if gpu_calls is not None:
+        parity = {"sites_checked": ncheck, "max_abs_dp_vs_oracle": worst, "ml_bytes_off_by_1lsb": nml, "tolerance": 1e-4}
+    return out, parity
+
+
+def roofline(precision, achieved, front_ms, front_launches):
+    """Roofline of the dominant kernel. `achieved` = ALGORITHMIC TFLOP/s (2 FLOP per MAC of conv1..conv4).
+    The split-half kernel issues three fp16 MFMAs per algorithmic MAC (hi*hi + hi*lo + lo*hi), so its executed
+    rate is 3x the algorithmic one; both are given, the peak is the fp16 dense MFMA peak."""
+    base = {"bound": "mfma", "unit": "TFLOP/s", "achieved": achieved,
+            "avg_launch_ms": front_ms / front_launches if front_launches else None, "launches": front_launches,
+            "traffic": None}
+    if precision == 1:
+        base.update(kernel="front_kernel_h (window+bn0+conv1..conv4, v_mfma_f32_16x16x32_f16 x3 split-half, fp32 accumulate)",
+                    peak=PEAK_FP16_MFMA_TFLOPS, frac=achieved / PEAK_FP16_MFMA_TFLOPS,
+                    executed=3.0 * achieved, frac_executed=3.0 * achieved / PEAK_FP16_MFMA_TFLOPS,
+                    vs_fp32_mfma_peak=achieved / PEAK_FP32_MFMA_TFLOPS)
+    else:
+        base.update(kernel="front_kernel (window+bn0+conv1..conv4, v_mfma_f32_16x16x4_f32)",
+                    peak=PEAK_FP32_MFMA_TFLOPS, frac=achieved / PEAK_FP32_MFMA_TFLOPS)
+    return base
 
 
 def main():
@@ -74,6 +112,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=96, help="reads per GPU batch (~15 kb each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
+                    help="front-kernel arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (e.g. front_waves=8)")
     args = ap.parse_args()
 
@@ -86,6 +126,7 @@ def main():
 
     reads = synth_reads(args.reads, seed=20250220 + rank, gc=0.36)
     mc = MethylationCaller(device=local_rank, timing=True)
+    mc.set_option("precision", args.precision)
     for kv in args.opt:
         k, v = kv.split("=")
         mc.set_option(k, int(v))
@@ -118,6 +159,7 @@ def main():
 
     sites_all, dt_max = hmdist.job_throughput(dist, sites_step, dt, device="cuda" if dist is not None else "cpu")
 
+    gpu_calls = mc.fetch() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     if rank == 0:
         front_ms = sum(tm["front_ms"])
         front_launches = sum(tm["front_launches"])
@@ -137,23 +179,19 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f16x3+f32acc" if args.precision == 1 else "f32",
             "data": "synthetic",
             "config": {"workload": "synthetic 30x-style HiFi reads (GC 0.36, ~15 kb log-normal, codev1 kinetics), "
                                    "all three contexts, batch resident in HBM; BASELINE.json configs[2] statistics",
                        "reads_per_gpu": args.reads, "bases_per_gpu": int(bases), "sites_per_gpu_step": int(sites_step),
                        "sites_by_context": {"CpG": sites_ctx[0], "CHG": sites_ctx[1], "CHH": sites_ctx[2]},
                        "parallelism": f"read-sharded x{world}, no collective"},
-            "roofline": {"bound": "mfma", "kernel": "front_kernel (window+bn0+conv1..conv4, fp32 MFMA 16x16x4)",
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "avg_launch_ms": front_ms / front_launches if front_launches else None,
-                         "launches": front_launches, "traffic": None},
+            "roofline": roofline(args.precision, achieved, front_ms, front_launches),
             "device_ms_timed_region": gpu_ms,
             "effective_tflops_all_layers": sum(2.0 * MAC_TOTAL[c] * sites_ctx[c] for c in range(3)) * args.steps / dt_max / 1e12,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(reads)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(reads, gpu_calls)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     mc.close()

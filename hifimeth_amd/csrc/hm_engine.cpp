@@ -97,7 +97,7 @@ struct hm_engine {
     int min_read_size = 1000;  // mod_options.cpp:10
     int64_t sub_batch = 65536;
     int front_waves = 8;
-    int precision = 0;  // 0 = fp32 MFMA (exact), 1 = split-half f16x3 MFMA with fp32 accumulate
+    int precision = 1;  // 1 = split-half f16x3 MFMA with fp32 accumulate (default), 0 = fp32 MFMA
     bool stamps_on = false;
     std::vector<unsigned long long> stamp_sum;
     bool timing = false;

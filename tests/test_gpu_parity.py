@@ -17,10 +17,14 @@ pytestmark = pytest.mark.gpu
 DP_TOL = 1e-4  # north_star: |dp| <= 1e-4 vs the fp32 CPU path
 
 
-@pytest.fixture(scope="module")
-def mc():
+@pytest.fixture(scope="module", params=[1, 0], ids=["f16x3", "fp32"])
+def mc(request):
+    """Every parity test runs in both arithmetic modes of the front kernel: split-half fp16 MFMA with fp32
+    accumulation (the default) and plain fp32 MFMA.  Both must meet the same |dp| <= 1e-4 bar."""
     from hifimeth_amd import MethylationCaller
     m = MethylationCaller(device=0, timing=True)
+    m.set_option("precision", request.param)
+    m.precision = request.param
     yield m
     m.close()
 
@@ -256,7 +260,7 @@ def test_split_half_precision_mode(mc, oracle, oracle_models):
         assert n > 3000
         print(f"f16x3: {n} sites, max|dp|={worst:.2e}, ML bytes differing by 1: {nml}")
     finally:
-        mc.set_option("precision", 0)
+        mc.set_option("precision", mc.precision)
 
 
 def test_empty_and_skipped(mc):
