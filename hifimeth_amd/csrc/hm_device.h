@@ -64,7 +64,7 @@ struct CtxWeights {
     const float* fc2_w;      // [2][256]
     const float* fc2_b;      // [2]
     const BnTables* bn;
-    const uint16_t* wfrag_h[4];  // conv1..conv4 as fp16 hi/lo fragments: [n-tile][k-block of 32][plane][lane][8]
+    const uint16_t* wfrag_h[9];  // conv1..conv8, fc1 as fp16 hi/lo fragments: [n-tile][k-block of 32][plane][lane][8]
     const BnTablesH* bn_h;
     int k1;
 };

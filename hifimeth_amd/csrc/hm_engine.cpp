@@ -204,7 +204,7 @@ void upload_model(hm_engine* e, int ctx, const HostModel& hmw) {
     dm.w.fc2_w = base + pk.fc2_w_off;
     dm.w.fc2_b = base + pk.fc2_b_off;
     dm.w.bn = reinterpret_cast<const BnTables*>(base + pk.bn_off);
-    for (int i = 0; i < 4; ++i) dm.w.wfrag_h[i] = reinterpret_cast<const uint16_t*>(base + pk.wfrag_h_off[i]);
+    for (int i = 0; i < 9; ++i) dm.w.wfrag_h[i] = reinterpret_cast<const uint16_t*>(base + pk.wfrag_h_off[i]);
     dm.w.bn_h = reinterpret_cast<const BnTablesH*>(base + pk.bn_h_off);
     dm.w.k1 = hmw.k1;
     dm.k1 = hmw.k1;
@@ -259,7 +259,10 @@ void run_cnn(hm_engine* e, int ctx, const Site* sites, const float* windows, int
             float* lg = e->d_logits.as<float>() + (sites ? 0 : 2 * off);
             float* pp = e->d_p.as<float>() + (sites ? 0 : off);
             uint8_t* mm = e->d_ml.as<uint8_t>() + (sites ? 0 : off);
-            launch_tail(e->stream, e->d_act4.as<float>(), m, dm.w, s_off, lg, pp, mm, e->num_cu, dbg, dbg_layer);
+            if (e->precision == 1)
+                launch_tail_h(e->stream, e->d_act4.as<float>(), m, dm.w, s_off, lg, pp, mm, e->num_cu, dbg, dbg_layer);
+            else
+                launch_tail(e->stream, e->d_act4.as<float>(), m, dm.w, s_off, lg, pp, mm, e->num_cu, dbg, dbg_layer);
             sp.end();
         }
     }

@@ -33,10 +33,13 @@ __device__ __forceinline__ void split4(const f32x4& v, half4& hi, half4& lo) {
 // K is processed in blocks of 32 (one MFMA).  Lane (li = l&15, lk = l>>4) owns 8 consecutive K elements:
 //   CIN >= 32 : channels c0 + 8*lk .. +7 of tap (32*kb)/CIN          (a block never straddles taps)
 //   CIN == 8  : all 8 channels of tap 4*kb + lk
-template <int NW_, int CIN_, int KT_, int COUT_, int LOUT_, int IRS_, int WM_, int WN_, int BR_ = 2>
+// S sites may be stacked along M (tail kernel): row m -> (site = m / LOUT, p = m % LOUT), site stride ISS halves.
+template <int NW_, int CIN_, int KT_, int COUT_, int LOUT_, int IRS_, int WM_, int WN_, int BR_ = 2, int S_ = 1,
+          int ISS_ = 0, int ROW0_ = 0>
 struct ConvH {
     static constexpr int NW = NW_, CIN = CIN_, KT = KT_, COUT = COUT_, LOUT = LOUT_, IRS = IRS_, WM = WM_, WN = WN_, BR = BR_;
-    static constexpr int M = LOUT;
+    static constexpr int S = S_, ISS = ISS_, ROW0 = ROW0_;
+    static constexpr int M = S * LOUT;
     static constexpr int MT = (M + 15) / 16;
     static constexpr int NT = COUT / 16;
     static constexpr int MTW = (MT + WM - 1) / WM;
@@ -69,7 +72,8 @@ struct ConvH {
         for (int i = 0; i < MTW; ++i) {
             int m = (wm * MTW + i) * 16 + li;
             m = m < M ? m : M - 1;
-            aoff[i] = 2 * m * IRS + lk_off;
+            const int site = S == 1 ? 0 : m / LOUT, p = S == 1 ? m : m - site * LOUT;
+            aoff[i] = site * ISS + (2 * p + ROW0) * IRS + lk_off;
         }
         f32x4 acc[MTW][NTW];
 #pragma unroll
@@ -325,6 +329,154 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         const int sn = s + gridDim.x;
         if (sn < n_sites && (int)threadIdx.x >= 256) build_window(sn, threadIdx.x - 256, 256);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// split-half tail: conv5 .. conv8, fc1 on fp16x3 MFMA; fc2 + softmax on the VALU in fp32
+// ------------------------------------------------------------------------------------------------
+template <int LOUT, int ORS, int OSS>
+struct EpiPlanesS {
+    half_t* hi;
+    half_t* lo;
+    const float* __restrict__ bias;
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        const int site = m / LOUT, p = m - site * LOUT;
+        half4 h, l;
+        split4(acc, h, l);
+        *reinterpret_cast<half4*>(hi + site * OSS + (p + 1) * ORS + col) = h;
+        *reinterpret_cast<half4*>(lo + site * OSS + (p + 1) * ORS + col) = l;
+    }
+};
+
+template <int HRS>
+struct EpiFc1 {  // ReLU, fp32 h[site][256] for the VALU fc2
+    float* out;
+    const float* __restrict__ bias;
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        *reinterpret_cast<float4*>(out + m * HRS + col) =
+            make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+    }
+};
+
+struct TailGeoH {
+    static constexpr int S = TAIL_SITES;
+    static constexpr int L4 = 25, L5 = 13, L6 = 7, L7 = 4, L8 = 2;
+    static constexpr int RS96 = 104, RS64 = 72, HRS = 260;  // halves, halves, floats
+    static constexpr int IN_SS = (L4 + 2) * RS96, C5_SS = (L5 + 2) * RS96, C6_SS = (L6 + 2) * RS96;
+    static constexpr int C7_SS = (L7 + 2) * RS64, C8_SS = (L8 + 2) * RS64;
+    static constexpr int P0 = S * IN_SS;  // plane size of buffer 0 (also conv6 / conv8 outputs)
+    static constexpr int P1 = S * C5_SS;  // plane size of buffer 1 (also conv7 output; fc1 output as floats)
+    static_assert(S * C6_SS <= P0 && S * C8_SS <= P0 && S * C7_SS <= P1 && S * HRS * 2 <= 2 * P1, "tail LDS plan");
+    static constexpr int LDS_HALVES = 2 * P0 + 2 * P1;
+};
+
+template <int S, int LOUT, int C>
+__device__ __forceinline__ void zero_pad_rows_h(half_t* hi, half_t* lo, int rs, int ss) {
+    for (int i = threadIdx.x; i < S * 2 * C; i += blockDim.x) {
+        const int site = i / (2 * C), rem = i - site * 2 * C;
+        const int which = rem / C, c = rem - which * C;
+        const int o = site * ss + (which ? (LOUT + 1) : 0) * rs + c;
+        hi[o] = (half_t)0.f;
+        lo[o] = (half_t)0.f;
+    }
+}
+
+__global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ act4, int n_sites, CtxWeights W,
+                                                      const Site* __restrict__ sites, float* __restrict__ logits,
+                                                      float* __restrict__ prob, uint8_t* __restrict__ ml,
+                                                      float* __restrict__ dbg, int dbg_layer) {
+    using T = TailGeoH;
+    constexpr int S = T::S, NW = 8;
+    __shared__ __attribute__((aligned(16))) half_t smem[T::LDS_HALVES];
+    half_t* h0 = smem;
+    half_t* l0 = smem + T::P0;
+    half_t* h1 = smem + 2 * T::P0;
+    half_t* l1 = smem + 2 * T::P0 + T::P1;
+    float* hfc = reinterpret_cast<float*>(h1);  // fc1 activations (fp32) reuse buffer 1
+    auto wf = [&](int i) { return reinterpret_cast<const half_t*>(W.wfrag_h[i]); };
+
+    for (int g = blockIdx.x; g * S < n_sites; g += gridDim.x) {
+        const int s0 = g * S;
+        const int nv = min(S, n_sites - s0);
+        // act4 [site][25][96] fp32 -> split planes 0, rows 1..25
+        for (int i = threadIdx.x; i < S * (ACT4_FLOATS / 4); i += NW * 64) {
+            const int site = i / (ACT4_FLOATS / 4), rem = (i - site * (ACT4_FLOATS / 4)) * 4;
+            const int pos = rem / C4_CH, c = rem - pos * C4_CH;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (site < nv) v = *reinterpret_cast<const float4*>(act4 + (size_t)(s0 + site) * ACT4_FLOATS + rem);
+            half4 h, l;
+            split4(f32x4{v.x, v.y, v.z, v.w}, h, l);  // act4 is post-ReLU already: the max() is a no-op
+            const int o = site * T::IN_SS + (pos + 1) * T::RS96 + c;
+            *reinterpret_cast<half4*>(h0 + o) = h;
+            *reinterpret_cast<half4*>(l0 + o) = l;
+        }
+        zero_pad_rows_h<S, T::L4, 96>(h0, l0, T::RS96, T::IN_SS);
+        __syncthreads();
+
+        ConvH<NW, 96, 3, 96, T::L5, T::RS96, 4, 2, 3, S, T::IN_SS, 0>::run(
+            h0, l0, wf(4), EpiPlanesS<T::L5, T::RS96, T::C5_SS>{h1, l1, W.bias[4]});
+        zero_pad_rows_h<S, T::L5, 96>(h1, l1, T::RS96, T::C5_SS);
+        __syncthreads();
+        if (dbg && dbg_layer == 5 && g == 0) dump_planes<T::L5, 96, T::RS96>(h1, l1, dbg);
+
+        ConvH<NW, 96, 3, 96, T::L6, T::RS96, 4, 2, 3, S, T::C5_SS, 0>::run(
+            h1, l1, wf(5), EpiPlanesS<T::L6, T::RS96, T::C6_SS>{h0, l0, W.bias[5]});
+        zero_pad_rows_h<S, T::L6, 96>(h0, l0, T::RS96, T::C6_SS);
+        __syncthreads();
+        if (dbg && dbg_layer == 6 && g == 0) dump_planes<T::L6, 96, T::RS96>(h0, l0, dbg);
+
+        ConvH<NW, 96, 3, 64, T::L7, T::RS96, 2, 4, 3, S, T::C6_SS, 0>::run(
+            h0, l0, wf(6), EpiPlanesS<T::L7, T::RS64, T::C7_SS>{h1, l1, W.bias[6]});
+        zero_pad_rows_h<S, T::L7, 64>(h1, l1, T::RS64, T::C7_SS);
+        __syncthreads();
+        if (dbg && dbg_layer == 7 && g == 0) dump_planes<T::L7, 64, T::RS64>(h1, l1, dbg);
+
+        ConvH<NW, 64, 3, 64, T::L8, T::RS64, 1, 4, 3, S, T::C7_SS, 0>::run(
+            h1, l1, wf(7), EpiPlanesS<T::L8, T::RS64, T::C8_SS>{h0, l0, W.bias[7]});
+        __syncthreads();
+        if (dbg && dbg_layer == 8 && g == 0) dump_planes<T::L8, 64, T::RS64>(h0, l0, dbg);
+
+        // fc1 as a 2-tap "conv" over conv8's two positions (k order l*64 + c; see hm_weights.cpp)
+        ConvH<NW, 64, 2, 256, 1, T::RS64, 1, 8, 2, S, T::C8_SS, 1>::run(h0, l0, wf(8), EpiFc1<T::HRS>{hfc, W.bias[8]});
+        __syncthreads();
+
+        // fc2 + softmax (mod_batch.cpp:46-64) in fp32: 16 lanes per site = 2 outputs x 8 partial sums
+        if (threadIdx.x < S * 16) {
+            const int site = threadIdx.x >> 4, o = (threadIdx.x >> 3) & 1, part = threadIdx.x & 7;
+            const float* h = hfc + site * T::HRS + part * 32;
+            const float* w2 = W.fc2_w + o * 256 + part * 32;
+            float sum = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) sum = fmaf(h[k], w2[k], sum);
+            sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 1, 64);
+            sum += W.fc2_b[o];
+            const float other = __shfl_xor(sum, 8, 64);
+            if ((threadIdx.x & 15) == 0 && site < nv) {
+                const float v0 = sum, v1 = other;
+                const float mx = fmaxf(v0, v1);
+                const float e0 = expf(v0 - mx), e1 = expf(v1 - mx);
+                const float p1 = e1 / (e0 + e1);
+                int q = (int)(255 * p1);
+                q = q > 255 ? 255 : q;
+                const int dst = sites ? sites[s0 + site].uidx : s0 + site;
+                logits[2 * (size_t)dst] = v0;
+                logits[2 * (size_t)dst + 1] = v1;
+                prob[dst] = p1;
+                ml[dst] = (uint8_t)q;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_tail_h(hipStream_t st, const float* act4, int n, const CtxWeights& w, const Site* sites, float* logits,
+                   float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer) {
+    if (n <= 0) return;
+    const int groups = (n + TAIL_SITES - 1) / TAIL_SITES;
+    hipLaunchKernelGGL(tail_kernel_h, dim3(min(groups, grid)), dim3(512), 0, st, act4, n, w, sites, logits, p, ml, dbg,
+                       dbg_layer);
 }
 
 void launch_front_h(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,

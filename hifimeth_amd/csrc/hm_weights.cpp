@@ -490,13 +490,14 @@ PackedModel pack_model(const HostModel& m) {
         memcpy(&lb, &l, 2);
         return (uint32_t)hb | ((uint32_t)lb << 16);
     };
-    for (int i = 0; i < 4; ++i) {  // conv1..conv4: [n-tile][k-block of 32][plane][lane][8 halves]
-        const int cin = kChannels[i], cout = kChannels[i + 1], k = m.kernel[i];
+    for (int i = 0; i < 9; ++i) {  // conv1..conv8, fc1: [n-tile][k-block of 32][plane][lane][8 halves]
+        const bool fc = i == 8;
+        const int cin = fc ? 64 : kChannels[i], cout = fc ? 256 : kChannels[i + 1], k = fc ? 2 : m.kernel[i];
         const int K_real = k * cin, KB = (K_real + 31) / 32, NT = cout / 16;
         align_blob(b);
         pk.wfrag_h_off[i] = b.size();
         std::vector<uint16_t> hw((size_t)NT * KB * 2 * 64 * 8);
-        const std::vector<float>& w = m.conv_w[i];
+        const std::vector<float>& w = fc ? m.fc1_w : m.conv_w[i];
         size_t o = 0;
         for (int nt = 0; nt < NT; ++nt)
             for (int kb = 0; kb < KB; ++kb)
@@ -506,6 +507,7 @@ PackedModel pack_model(const HostModel& m) {
                             const int kk = kb * 32 + 8 * (lane >> 4) + j;  // kk = tap*CIN + c
                             const int co = nt * 16 + (lane & 15);
                             uint32_t hl = 0;
+                            // conv: W[co][c][tap]; fc1: fc1_w[co][c*2 + l] with kk = l*64 + c (same index formula)
                             if (kk < K_real) hl = split(w[((size_t)co * cin + kk % cin) * k + kk / cin]);
                             hw[o++] = (uint16_t)(plane ? hl >> 16 : hl & 0xffffu);
                         }

@@ -23,7 +23,7 @@ struct HostModel {
 struct PackedModel {
     std::vector<float> blob;
     size_t wfrag_off[9], bias_off[9], fc2_w_off, fc2_b_off, bn_off;
-    size_t wfrag_h_off[4], bn_h_off;  // fp16 hi/lo data, offsets in floats like the others
+    size_t wfrag_h_off[9], bn_h_off;  // fp16 hi/lo data, offsets in floats like the others
 };
 
 // <dir>/<name>.hmw, else <dir>/<name>.onnx (the reference's model_dir layout, mod_main.cpp:76,85,94)
