@@ -245,12 +245,13 @@ void run_cnn(hm_engine* e, int ctx, const Site* sites, const float* windows, int
             Span sp(e, K_FRONT0 + ctx, m);
             if (e->precision == 1)
                 launch_front_h(e->stream, dm.k1, s_off, m, e->d_reads.as<ReadDesc>(), e->d_bases.as<uint8_t>(),
-                               e->d_kin.as<uint32_t>(), w_off, dm.w, e->d_act4.as<float>(), e->num_cu, dbg, dbg_layer);
+                               e->d_kin.as<uint32_t>(), w_off, dm.w, e->d_act4.as<float>(), e->num_cu, dbg, dbg_layer,
+                               e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr);
             else
                 launch_front(e->stream, dm.k1, s_off, m, e->d_reads.as<ReadDesc>(), e->d_bases.as<uint8_t>(),
                              e->d_kin.as<uint32_t>(), w_off, dm.w, e->d_act4.as<float>(), e->num_cu, dbg, dbg_layer,
                              e->front_waves, e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr);
-            if (e->stamps_on && e->precision == 0) accumulate_stamps(e);
+            if (e->stamps_on) accumulate_stamps(e);
             sp.end();
         }
         {

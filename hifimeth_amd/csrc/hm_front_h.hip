@@ -12,6 +12,7 @@
 #include <utility>
 
 #include "hm_kernels.h"
+#include "hm_stamp.h"
 
 namespace hm {
 
@@ -20,14 +21,17 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half_t;
 
+typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
+
+// ReLU, then x = hi + lo with packed round-toward-zero conversions (v_cvt_pkrtz_f16_f32): hi keeps the top 11
+// bits, the residual x - hi is exact in fp32 and lo keeps its top 11 bits -> |x - (hi + lo)| <= 2^-21 |x|.
 __device__ __forceinline__ void split4(const f32x4& v, half4& hi, half4& lo) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float x = fmaxf(v[r], 0.f);  // ReLU
-        const half_t h = (half_t)x;
-        hi[r] = h;
-        lo[r] = (half_t)(x - (float)h);
-    }
+    const float x0 = fmaxf(v[0], 0.f), x1 = fmaxf(v[1], 0.f), x2 = fmaxf(v[2], 0.f), x3 = fmaxf(v[3], 0.f);
+    const pk2 h01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
+    const pk2 l01 = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h01[0], x1 - (float)h01[1]);
+    const pk2 l23 = __builtin_amdgcn_cvt_pkrtz(x2 - (float)h23[0], x3 - (float)h23[1]);
+    hi[0] = (half_t)h01[0]; hi[1] = (half_t)h01[1]; hi[2] = (half_t)h23[0]; hi[3] = (half_t)h23[1];
+    lo[0] = (half_t)l01[0]; lo[1] = (half_t)l01[1]; lo[2] = (half_t)l23[0]; lo[3] = (half_t)l23[1];
 }
 
 // K is processed in blocks of 32 (one MFMA).  Lane (li = l&15, lk = l>>4) owns 8 consecutive K elements:
@@ -119,7 +123,9 @@ struct ConvH {
                     x[RA ^ 1][i][1] = *reinterpret_cast<const half8*>(in_lo + bo + aoff[i]);
                 }
             }
+#if !defined(HM_H_SCHED) || HM_H_SCHED == 0
             __builtin_amdgcn_sched_barrier(0);
+#endif
             // the three partial products, outermost so that an accumulator is revisited only after
             // MTW*NTW other MFMAs (no back-to-back dependent MFMAs)
 #pragma unroll
@@ -130,6 +136,26 @@ struct ConvH {
                     for (int j = 0; j < NTW; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[RB][j][pr == 2 ? 1 : 0], x[RA][i][pr == 1 ? 1 : 0],
                                                                            acc[i][j], 0, 0, 0);
+#if defined(HM_H_SCHED) && HM_H_SCHED == 2
+            // one load (VMEM or LDS, with its address VALU) in the shadow of every MPS MFMAs
+            {
+                constexpr int NM = 3 * MTW * NTW, NL = 2 * NTW + 2 * MTW;
+                constexpr int MPS = NM / NL > 0 ? NM / NL : 1;
+#pragma unroll
+                for (int t = 0; t < 2 * NTW; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MPS, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < 2 * MTW; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MPS, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         constexpr int UN = BR % 2 == 0 ? BR : 2 * BR;
@@ -217,14 +243,28 @@ __device__ __forceinline__ void dump_planes(const half_t* hi, const half_t* lo, 
     }
 }
 
-template <int K1, bool RAW>
+template <int K1, bool RAW, bool STAMP = false>
 __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ sites, int n_sites,
                                                        const ReadDesc* __restrict__ reads,
                                                        const uint8_t* __restrict__ bases,
                                                        const uint32_t* __restrict__ kin,
                                                        const float* __restrict__ windows, CtxWeights W,
-                                                       float* __restrict__ act4, float* __restrict__ dbg, int dbg_layer) {
+                                                       float* __restrict__ act4, float* __restrict__ dbg, int dbg_layer,
+                                                       unsigned long long* __restrict__ stamps) {
     using G = GeoH<K1>;
+    unsigned long long tacc[N_STAMP];
+    unsigned long long tprev = 0;
+    if (STAMP) {
+#pragma unroll
+        for (int i = 0; i < N_STAMP; ++i) tacc[i] = 0;
+    }
+    auto mk = [&](int ph) __attribute__((always_inline)) {
+        if (STAMP) {
+            const unsigned long long t_ = hm_stamp();
+            tacc[ph] += t_ - tprev;
+            tprev = t_;
+        }
+    };
     constexpr int NW = 8;
     __shared__ __attribute__((aligned(16))) half_t smem[G::LDS_HALVES];
     half_t* a_hi = smem;
@@ -299,35 +339,51 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
 
     if ((int)blockIdx.x < n_sites) build_window(blockIdx.x, threadIdx.x, NW * 64);
     for (int s = blockIdx.x; s < n_sites; s += gridDim.x) {
+        if (STAMP) tprev = hm_stamp();
+        mk(0);
         __syncthreads();  // window of site s complete; previous conv4 done with planes A
+        mk(1);
 
         // conv1: window (planes B) -> planes A
         ConvH<NW, 8, G::KT1, 128, G::L1, G::WRS, 2, 4, 2>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[0]),
                                                              EpiPlanes<G::RS>{a_hi, a_lo, W.bias[0]});
+        mk(4);
         zero_rows_h<128>(a_hi, a_lo, 0, G::L1 + 1, G::RS);
         __syncthreads();
+        mk(5);
         if (dbg && dbg_layer == 1 && s == 0) dump_planes<G::L1, 128, G::RS>(a_hi, a_lo, dbg);
 
         // conv2: planes A -> planes B
-        ConvH<NW, 128, 3, 128, G::L2, G::RS, 2, 4, 2>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]),
+        ConvH<NW, 128, 3, 128, G::L2, G::RS, 1, 8, 3>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]),
                                                            EpiPlanes<G::RS>{b_hi, b_lo, W.bias[1]});
+        mk(8);
         zero_rows_h<128>(b_hi, b_lo, 0, G::L2 + 1, G::RS);
         __syncthreads();
+        mk(9);
         if (dbg && dbg_layer == 2 && s == 0) dump_planes<G::L2, 128, G::RS>(b_hi, b_lo, dbg);
 
         // conv3: planes B -> planes A
-        ConvH<NW, 128, 3, 128, G::L3, G::RS, 2, 4, 3>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
+        ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 4>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
                                                            EpiPlanes<G::RS>{a_hi, a_lo, W.bias[2]});
+        mk(12);
         zero_rows_h<128>(a_hi, a_lo, 0, G::L3 + 1, G::RS);
         __syncthreads();
+        mk(13);
         if (dbg && dbg_layer == 3 && s == 0) dump_planes<G::L3, 128, G::RS>(a_hi, a_lo, dbg);
 
-        // conv4: planes A -> act4[s] (fp32, hand-off to the fp32 tail kernel) on the first 4 waves;
-        // the other 4 build the next site's window in planes B meanwhile
-        ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 2, 2, 4>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]),
+        // conv4: planes A -> act4[s] (fp32, hand-off to the tail kernel) on 6 waves (one 16-channel tile column
+        // each, weights 5 k-blocks ahead); the other 2 build the next site's window in planes B meanwhile
+        ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 6>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]),
                                                             EpiGlobalF<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]});
+        mk(16);
         const int sn = s + gridDim.x;
-        if (sn < n_sites && (int)threadIdx.x >= 256) build_window(sn, threadIdx.x - 256, 256);
+        if (sn < n_sites && (int)threadIdx.x >= 384) build_window(sn, threadIdx.x - 384, 128);
+        mk(17);
+    }
+    if (STAMP && (threadIdx.x & 63) == 0) {
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * N_STAMP;
+#pragma unroll
+        for (int i = 0; i < N_STAMP; ++i) o[i] = tacc[i];
     }
 }
 
@@ -481,14 +537,17 @@ void launch_tail_h(hipStream_t st, const float* act4, int n, const CtxWeights& w
 
 void launch_front_h(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
                     const uint32_t* kin, const float* windows, const CtxWeights& w, float* act4, int grid, float* dbg,
-                    int dbg_layer) {
+                    int dbg_layer, unsigned long long* stamps) {
     if (n <= 0) return;
     const dim3 g(min(n, grid)), b(512);
     const bool raw = windows == nullptr;
-#define HM_FRONT_H(K1, RAW) \
-    hipLaunchKernelGGL((front_kernel_h<K1, RAW>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer)
-    if (k1 == 11) { if (raw) HM_FRONT_H(11, true); else HM_FRONT_H(11, false); }
-    else { if (raw) HM_FRONT_H(13, true); else HM_FRONT_H(13, false); }
+#define HM_FRONT_H(K1, RAW, ST)                                                                                       \
+    hipLaunchKernelGGL((front_kernel_h<K1, RAW, ST>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, \
+                       dbg_layer, stamps)
+    if (stamps && raw) {
+        if (k1 == 11) HM_FRONT_H(11, true, true); else HM_FRONT_H(13, true, true);
+    } else if (k1 == 11) { if (raw) HM_FRONT_H(11, true, false); else HM_FRONT_H(11, false, false); }
+    else { if (raw) HM_FRONT_H(13, true, false); else HM_FRONT_H(13, false, false); }
 #undef HM_FRONT_H
 }
 

@@ -10,6 +10,7 @@
 //
 // Written for wave64 / gfx950 only.
 #include "hm_kernels.h"
+#include "hm_stamp.h"
 
 #include <type_traits>
 #include <utility>
@@ -548,15 +549,7 @@ struct Conv {
     }
 };
 
-// diagnostic builds only: shader-clock stamp (cdna_hip_programming.md section 7, "In-kernel stamps")
-__device__ __forceinline__ unsigned long long hm_stamp() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-constexpr int N_STAMP = 20;
+
 
 // ReLU (bias already in the accumulator); 4 consecutive channels of position m -> LDS channels-last with
 // row stride ORS / site stride OSS (physical row p+1)

@@ -9,6 +9,7 @@ names = ["window build", "barrier"] + [f"conv{l} {w}" for l in (1, 2, 3, 4) for 
 reads = synth_reads(int(sys.argv[1]) if len(sys.argv) > 1 else 48, seed=20250220)
 with MethylationCaller(timing=True) as mc:
     mc.set_option("front_waves", 8)
+    mc.set_option("precision", int(os.environ.get("HM_PRECISION", "1")))
     mc.submit_all(reads); mc.upload(); mc.run(); mc.sync()
     mc.set_option("stamps", 1)
     mc.run(); mc.sync()
