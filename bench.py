@@ -94,6 +94,16 @@ def roofline(precision, achieved, front_ms, front_launches):
     base = {"bound": "mfma", "unit": "TFLOP/s", "achieved": achieved,
             "avg_launch_ms": front_ms / front_launches if front_launches else None, "launches": front_launches,
             "traffic": None}
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (cannot run inside this process);
+    # the committed summary of the last such pass is quoted, with its source, when present
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        if precision == 1:
+            t = pmc["front_kernel_h<13> per launch (65536 sites)"]
+            base["traffic"] = t["hbm_read_bytes_corrected"] + t["hbm_write_bytes"]
+            base["traffic_source"] = "profiles/r01_pmc_summary.json (front_kernel_h<13>, 65536 sites per launch; FETCH_SIZE x2 corrected)"
+    except (OSError, KeyError, ValueError):
+        pass
     if precision == 1:
         base.update(kernel="front_kernel_h (window+bn0+conv1..conv4, v_mfma_f32_16x16x32_f16 x3 split-half, fp32 accumulate)",
                     peak=PEAK_FP16_MFMA_TFLOPS, frac=achieved / PEAK_FP16_MFMA_TFLOPS,
@@ -122,10 +132,15 @@ def main():
     from hifimeth_amd.synth import synth_reads
 
     rank, local_rank, world = hmdist.env_world()
-    dist = hmdist.init_process_group("nccl") if world > 1 else None
+    # HM_DIST_BACKEND=gloo lets the multi-rank path be rehearsed on a box with fewer GPUs than ranks
+    backend = os.environ.get("HM_DIST_BACKEND", "nccl")
+    dist = hmdist.init_process_group(backend) if world > 1 else None
+    on_gpu_collectives = dist is not None and backend == "nccl"
 
     reads = synth_reads(args.reads, seed=20250220 + rank, gc=0.36)
-    mc = MethylationCaller(device=local_rank, timing=True)
+    import torch
+    ndev = torch.cuda.device_count()
+    mc = MethylationCaller(device=local_rank % max(ndev, 1), timing=True)
     mc.set_option("precision", args.precision)
     for kv in args.opt:
         k, v = kv.split("=")
@@ -136,7 +151,6 @@ def main():
 
     def barrier():
         if dist is not None:
-            import torch
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -157,7 +171,7 @@ def main():
     tm = mc.timing()
     bases = sum(r.l_qseq for r in reads if r.has_kinetics() and r.l_qseq >= 1000)
 
-    sites_all, dt_max = hmdist.job_throughput(dist, sites_step, dt, device="cuda" if dist is not None else "cpu")
+    sites_all, dt_max = hmdist.job_throughput(dist, sites_step, dt, device="cuda" if on_gpu_collectives else "cpu")
 
     gpu_calls = mc.fetch() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     if rank == 0:
