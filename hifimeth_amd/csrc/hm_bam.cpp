@@ -1,0 +1,460 @@
+// hm_bam.cpp -- see hm_bam.h
+#include "hm_bam.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
+
+namespace hmbam {
+
+namespace {
+
+template <class F>
+void parallel_for(int n, int threads, F f) {
+    threads = std::max(1, std::min(threads, n));
+    if (threads == 1) {
+        for (int i = 0; i < n; ++i) f(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&] {
+            for (int i = next++; i < n; i = next++) f(i);
+        });
+    for (auto& t : pool) t.join();
+}
+
+inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline void wr16(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+inline void wr32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+
+constexpr size_t BGZF_MAX_PAYLOAD = 0xff00;  // uncompressed bytes per block (as htslib)
+constexpr int BATCH_BLOCKS = 256;
+
+const uint8_t kEofBlock[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43,
+                               0x02, 0x00, 0x1b, 0x00, 0x03, 0x00, 0, 0, 0, 0, 0, 0, 0, 0};
+
+struct RawBlock {
+    std::vector<uint8_t> comp;  // deflate payload
+    uint32_t crc = 0, isize = 0;
+    std::vector<uint8_t> out;
+    bool bad = false;
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// BGZF
+// ------------------------------------------------------------------------------------------------
+BgzfReader::BgzfReader(const std::string& path, int threads) : threads_(threads) {
+    fp_ = fopen(path.c_str(), "rb");
+    if (!fp_) err_ = "cannot open " + path;
+}
+
+BgzfReader::~BgzfReader() {
+    if (fp_) fclose(fp_);
+}
+
+bool BgzfReader::refill() {
+    std::vector<RawBlock> blocks;
+    while ((int)blocks.size() < BATCH_BLOCKS) {
+        uint8_t hdr[12];
+        const size_t got = fread(hdr, 1, 12, fp_);
+        if (got == 0) {
+            eof_ = true;
+            break;
+        }
+        if (got != 12 || hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) {
+            err_ = "not a BGZF file (bad gzip member header)";
+            return false;
+        }
+        const int xlen = rd16(hdr + 10);
+        std::vector<uint8_t> extra((size_t)xlen);
+        if (fread(extra.data(), 1, (size_t)xlen, fp_) != (size_t)xlen) {
+            err_ = "truncated BGZF block";
+            return false;
+        }
+        int bsize = -1;
+        for (int i = 0; i + 4 <= xlen;) {
+            const int slen = rd16(extra.data() + i + 2);
+            if (extra[(size_t)i] == 'B' && extra[(size_t)i + 1] == 'C' && slen == 2) bsize = rd16(extra.data() + i + 4);
+            i += 4 + slen;
+        }
+        if (bsize < 0) {
+            err_ = "BGZF block without BC field";
+            return false;
+        }
+        const long clen = (long)bsize + 1 - 12 - xlen - 8;
+        if (clen < 0) {
+            err_ = "corrupt BGZF block size";
+            return false;
+        }
+        RawBlock b;
+        b.comp.resize((size_t)clen);
+        uint8_t tail[8];
+        if (fread(b.comp.data(), 1, (size_t)clen, fp_) != (size_t)clen || fread(tail, 1, 8, fp_) != 8) {
+            err_ = "truncated BGZF block";
+            return false;
+        }
+        b.crc = rd32(tail);
+        b.isize = rd32(tail + 4);
+        blocks.push_back(std::move(b));
+    }
+    parallel_for((int)blocks.size(), threads_, [&](int i) {
+        RawBlock& b = blocks[(size_t)i];
+        b.out.resize(b.isize);
+        if (b.isize == 0) return;
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) {
+            b.bad = true;
+            return;
+        }
+        zs.next_in = b.comp.data();
+        zs.avail_in = (uInt)b.comp.size();
+        zs.next_out = b.out.data();
+        zs.avail_out = (uInt)b.out.size();
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END || zs.total_out != b.isize || crc32(0L, b.out.data(), (uInt)b.out.size()) != b.crc) b.bad = true;
+    });
+    buf_.erase(buf_.begin(), buf_.begin() + (long)pos_);
+    pos_ = 0;
+    for (auto& b : blocks) {
+        if (b.bad) {
+            err_ = "BGZF block failed to inflate (corrupt data or CRC mismatch)";
+            return false;
+        }
+        buf_.insert(buf_.end(), b.out.begin(), b.out.end());
+    }
+    return true;
+}
+
+bool BgzfReader::read(void* dst, size_t n) {
+    while (buf_.size() - pos_ < n) {
+        if (eof_) {
+            if (buf_.size() - pos_ != 0 && err_.empty()) err_ = "truncated file";
+            return false;
+        }
+        if (!refill()) return false;
+    }
+    memcpy(dst, buf_.data() + pos_, n);
+    pos_ += n;
+    return true;
+}
+
+BgzfWriter::BgzfWriter(const std::string& path, int threads, int level) : threads_(threads), level_(level) {
+    fp_ = fopen(path.c_str(), "wb");
+    if (!fp_) err_ = "cannot create " + path;
+}
+
+BgzfWriter::~BgzfWriter() {
+    if (fp_) fclose(fp_);
+}
+
+void BgzfWriter::write(const void* src, size_t n) {
+    const uint8_t* p = static_cast<const uint8_t*>(src);
+    buf_.insert(buf_.end(), p, p + n);
+    if (buf_.size() >= BGZF_MAX_PAYLOAD * BATCH_BLOCKS) flush_blocks(false);
+}
+
+void BgzfWriter::flush_blocks(bool all) {
+    if (!fp_) return;
+    const size_t nfull = buf_.size() / BGZF_MAX_PAYLOAD;
+    const size_t nblk = nfull + ((all && buf_.size() % BGZF_MAX_PAYLOAD) ? 1 : 0);
+    if (nblk == 0) return;
+    std::vector<std::vector<uint8_t>> out(nblk);
+    std::atomic<bool> bad{false};
+    parallel_for((int)nblk, threads_, [&](int i) {
+        const size_t off = (size_t)i * BGZF_MAX_PAYLOAD;
+        const size_t len = std::min(BGZF_MAX_PAYLOAD, buf_.size() - off);
+        std::vector<uint8_t>& o = out[(size_t)i];
+        o.resize(18 + compressBound((uLong)len) + 8);
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+            bad = true;
+            return;
+        }
+        zs.next_in = const_cast<uint8_t*>(buf_.data() + off);
+        zs.avail_in = (uInt)len;
+        zs.next_out = o.data() + 18;
+        zs.avail_out = (uInt)(o.size() - 18 - 8);
+        const int rc = deflate(&zs, Z_FINISH);
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END || 18 + clen + 8 > 0x10000) {
+            bad = true;
+            return;
+        }
+        static const uint8_t head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43, 0x02, 0x00};
+        memcpy(o.data(), head, 16);
+        wr16(o.data() + 16, (uint32_t)(18 + clen + 8 - 1));
+        wr32(o.data() + 18 + clen, (uint32_t)crc32(0L, buf_.data() + off, (uInt)len));
+        wr32(o.data() + 18 + clen + 4, (uint32_t)len);
+        o.resize(18 + clen + 8);
+    });
+    if (bad) {
+        err_ = "deflate failed";
+        return;
+    }
+    for (auto& o : out)
+        if (fwrite(o.data(), 1, o.size(), fp_) != o.size()) err_ = "write error";
+    const size_t consumed = std::min(buf_.size(), nblk * BGZF_MAX_PAYLOAD);
+    buf_.erase(buf_.begin(), buf_.begin() + (long)consumed);
+}
+
+bool BgzfWriter::close() {
+    if (!fp_) return false;
+    flush_blocks(true);
+    if (fwrite(kEofBlock, 1, sizeof kEofBlock, fp_) != sizeof kEofBlock) err_ = "write error";
+    if (fclose(fp_) != 0) err_ = "close error";
+    fp_ = nullptr;
+    return err_.empty();
+}
+
+// ------------------------------------------------------------------------------------------------
+// BAM
+// ------------------------------------------------------------------------------------------------
+int32_t BamRecord::l_qseq() const { return (int32_t)rd32(data.data() + 16); }
+uint16_t BamRecord::flag() const { return rd16(data.data() + 14); }
+int BamRecord::n_cigar() const { return rd16(data.data() + 12); }
+const uint8_t* BamRecord::seq4() const { return data.data() + 32 + l_read_name() + 4 * (size_t)n_cigar(); }
+size_t BamRecord::aux_offset() const {
+    const size_t L = (size_t)l_qseq();
+    return 32 + (size_t)l_read_name() + 4 * (size_t)n_cigar() + (L + 1) / 2 + L;
+}
+
+bool read_header(BgzfReader& in, BamHeader& h, std::string& err) {
+    uint8_t b[8];
+    if (!in.read(b, 8) || memcmp(b, "BAM\1", 4) != 0) {
+        err = in.error().empty() ? "not a BAM file" : in.error();
+        return false;
+    }
+    const uint32_t l_text = rd32(b + 4);
+    h.text.resize(l_text);
+    if (l_text && !in.read(&h.text[0], l_text)) { err = "truncated BAM header"; return false; }
+    while (!h.text.empty() && h.text.back() == '\0') h.text.pop_back();
+    if (!in.read(b, 4)) { err = "truncated BAM header"; return false; }
+    const uint32_t n_ref = rd32(b);
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (!in.read(b, 4)) { err = "truncated BAM header"; return false; }
+        const uint32_t ln = rd32(b);
+        std::string name(ln, '\0');
+        if ((ln && !in.read(&name[0], ln)) || !in.read(b, 4)) { err = "truncated BAM header"; return false; }
+        while (!name.empty() && name.back() == '\0') name.pop_back();
+        h.refs.emplace_back(name, (int32_t)rd32(b));
+    }
+    return true;
+}
+
+void write_header(BgzfWriter& out, const BamHeader& h) {
+    std::vector<uint8_t> b;
+    auto put32 = [&](uint32_t v) { uint8_t t[4]; wr32(t, v); b.insert(b.end(), t, t + 4); };
+    b.insert(b.end(), {'B', 'A', 'M', 1});
+    put32((uint32_t)h.text.size());
+    b.insert(b.end(), h.text.begin(), h.text.end());
+    put32((uint32_t)h.refs.size());
+    for (auto& r : h.refs) {
+        put32((uint32_t)r.first.size() + 1);
+        b.insert(b.end(), r.first.begin(), r.first.end());
+        b.push_back(0);
+        put32((uint32_t)r.second);
+    }
+    out.write(b.data(), b.size());
+}
+
+bool read_record(BgzfReader& in, BamRecord& r, std::string& err) {
+    uint8_t b[4];
+    if (!in.read(b, 4)) {
+        err = in.error();
+        return false;  // clean EOF when err is empty
+    }
+    const uint32_t bs = rd32(b);
+    if (bs < 32 || bs > (1u << 30)) { err = "corrupt BAM record size"; return false; }
+    r.data.resize(bs);
+    if (!in.read(r.data.data(), bs)) { err = in.error().empty() ? "truncated BAM record" : in.error(); return false; }
+    if (r.aux_offset() > r.data.size()) { err = "corrupt BAM record"; return false; }
+    return true;
+}
+
+void write_record(BgzfWriter& out, const BamRecord& r) {
+    uint8_t b[4];
+    wr32(b, (uint32_t)r.data.size());
+    out.write(b, 4);
+    out.write(r.data.data(), r.data.size());
+}
+
+static int aux_elem_size(char t) {
+    switch (t) {
+    case 'A': case 'c': case 'C': return 1;
+    case 's': case 'S': return 2;
+    case 'i': case 'I': case 'f': return 4;
+    case 'd': return 8;
+    default: return 0;
+    }
+}
+
+bool next_aux(const uint8_t*& p, const uint8_t* end, AuxField& f) {
+    if (end - p < 3) return false;
+    const uint8_t* s = p;
+    f.tag[0] = (char)s[0];
+    f.tag[1] = (char)s[1];
+    f.type = (char)s[2];
+    f.subtype = 0;
+    f.count = 0;
+    s += 3;
+    if (f.type == 'Z' || f.type == 'H') {
+        f.payload = s;
+        while (s < end && *s) ++s;
+        if (s >= end) return false;
+        ++s;
+    } else if (f.type == 'B') {
+        if (end - s < 5) return false;
+        f.subtype = (char)s[0];
+        f.count = rd32(s + 1);
+        const int es = aux_elem_size(f.subtype);
+        s += 5;
+        if (es == 0 || (uint64_t)(end - s) < (uint64_t)es * f.count) return false;
+        f.payload = s;
+        s += (size_t)es * f.count;
+    } else {
+        const int es = aux_elem_size(f.type);
+        if (es == 0 || end - s < es) return false;
+        f.payload = s;
+        s += es;
+    }
+    f.total = (size_t)(s - p);
+    p = s;
+    return true;
+}
+
+KineticsView kinetics_of(const BamRecord& r) {
+    KineticsView kv{{nullptr, nullptr, nullptr, nullptr}, {1, 1, 1, 1}};
+    static const char* names[4] = {"fi", "fp", "ri", "rp"};
+    const uint8_t* p = r.data.data() + r.aux_offset();
+    const uint8_t* end = r.data.data() + r.data.size();
+    AuxField f;
+    while (p < end && next_aux(p, end, f)) {
+        for (int k = 0; k < 4; ++k) {
+            if (f.tag[0] != names[k][0] || f.tag[1] != names[k][1] || kv.arr[k]) continue;
+            // first occurrence wins (bam_aux_get); must be B:C or B:S with l_qseq elements (bam_info.cpp:443-453)
+            if (f.type == 'B' && (f.subtype == 'C' || f.subtype == 'S') && f.count == (uint32_t)r.l_qseq()) {
+                kv.arr[k] = f.payload;
+                kv.width[k] = f.subtype == 'C' ? 1 : 2;
+            } else {
+                kv.arr[k] = nullptr;
+            }
+        }
+    }
+    return kv;
+}
+
+char fwd_strand_base(const BamRecord& r, int k) {
+    static const char dec[16] = {'=', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W', 'Y', 'H', 'K', 'D', 'B', 'N'};
+    const int L = r.l_qseq();
+    const uint8_t* s = r.seq4();
+    if (r.flag() & 16) {  // stored reverse strand: complement of the mirrored position
+        const int i = L - 1 - k;
+        const int nib = (s[i >> 1] >> ((~i & 1) << 2)) & 15;
+        switch (nib) {
+        case 1: return 'T';
+        case 2: return 'G';
+        case 4: return 'C';
+        case 8: return 'A';
+        default: return 'N';
+        }
+    }
+    const int nib = (s[k >> 1] >> ((~k & 1) << 2)) & 15;
+    return dec[nib];
+}
+
+bool apply_calls(BamRecord& r, const hm_call_t* calls, size_t n, bool keep_kinetics, std::string& err) {
+    // 1. copy the aux block without fi/ri/fp/rp (unless -k) and without MM / ML (build_mod_bam.cpp:87-109)
+    const size_t aux0 = r.aux_offset();
+    std::vector<uint8_t> aux;
+    const uint8_t* p = r.data.data() + aux0;
+    const uint8_t* end = r.data.data() + r.data.size();
+    AuxField f;
+    const uint8_t* mn = nullptr;  // an existing MN tag is updated, like bam_aux_update_int does
+    while (p < end) {
+        const uint8_t* start = p;
+        if (!next_aux(p, end, f)) {
+            err = "corrupt aux data";
+            return false;
+        }
+        const bool kin = (f.tag[0] == 'f' || f.tag[0] == 'r') && (f.tag[1] == 'i' || f.tag[1] == 'p');
+        const bool oldmod = f.tag[0] == 'M' && (f.tag[1] == 'M' || f.tag[1] == 'L');
+        if ((kin && !keep_kinetics) || oldmod) continue;
+        if (f.tag[0] == 'M' && f.tag[1] == 'N' && n > 0) {
+            mn = start;
+            continue;  // re-appended below with the new value
+        }
+        aux.insert(aux.end(), start, start + f.total);
+    }
+    (void)mn;
+    if (n > 0) {
+        // 2. MM:Z  "C+m" {",delta"} ";" "G-m" {",delta"} ";"   delta = number of skipped C (G) on the forward
+        //    strand since the previous call (build_mod_bam.cpp:134-168)
+        std::string mm;
+        size_t nf = 0;
+        while (nf < n && calls[nf].strand == 0) ++nf;
+        for (int strand = 0; strand < 2; ++strand) {
+            mm += strand == 0 ? "C+m" : "G-m";
+            const char base = strand == 0 ? 'C' : 'G';
+            const hm_call_t* c = strand == 0 ? calls : calls + nf;
+            const size_t m = strand == 0 ? nf : n - nf;
+            int last = 0;
+            for (size_t i = 0; i < m; ++i) {
+                if (c[i].strand != strand || (i + 1 < m && c[i].qoff >= c[i + 1].qoff) || c[i].qoff < last ||
+                    c[i].qoff >= r.l_qseq() || fwd_strand_base(r, c[i].qoff) != base) {
+                    err = "calls are not strictly increasing per strand or do not sit on C/G";
+                    return false;
+                }
+                int delta = 0;
+                for (int k = last; k < c[i].qoff; ++k) delta += fwd_strand_base(r, k) == base;
+                mm += ',';
+                mm += std::to_string(delta);
+                last = c[i].qoff + 1;
+            }
+            mm += ';';
+        }
+        aux.insert(aux.end(), {'M', 'M', 'Z'});
+        aux.insert(aux.end(), mm.begin(), mm.end());
+        aux.push_back(0);
+        // 3. ML:B:C  forward-strand probabilities then reverse-strand ones (build_mod_bam.cpp:170-176,200)
+        aux.insert(aux.end(), {'M', 'L', 'B', 'C'});
+        uint8_t cnt[4];
+        wr32(cnt, (uint32_t)n);
+        aux.insert(aux.end(), cnt, cnt + 4);
+        for (size_t i = 0; i < n; ++i) aux.push_back(calls[i].scaled_prob);
+        // 4. MN = l_qseq in the smallest unsigned type that holds it (bam_aux_update_int, build_mod_bam.cpp:222-224)
+        const uint32_t L = (uint32_t)r.l_qseq();
+        aux.insert(aux.end(), {'M', 'N'});
+        if (L <= 0xff) {
+            aux.push_back('C');
+            aux.push_back((uint8_t)L);
+        } else if (L <= 0xffff) {
+            aux.push_back('S');
+            uint8_t t[2];
+            wr16(t, L);
+            aux.insert(aux.end(), t, t + 2);
+        } else {
+            aux.push_back('I');
+            aux.insert(aux.end(), cnt, cnt);  // (no-op, keeps the layout explicit)
+            uint8_t t[4];
+            wr32(t, L);
+            aux.insert(aux.end(), t, t + 4);
+        }
+    }
+    r.data.resize(aux0);
+    r.data.insert(r.data.end(), aux.begin(), aux.end());
+    return true;
+}
+
+}  // namespace hmbam

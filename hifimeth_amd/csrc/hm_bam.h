@@ -1,0 +1,104 @@
+// hm_bam.h -- minimal BGZF + BAM record codec and the MM/ML/MN tag writer for the `call` front end.
+// htslib is not available in this image, so the container formats are implemented directly on zlib:
+//   BGZF : SAMv1 section 4.1 (gzip members with a 'BC' extra field, <= 64 KiB each, 28-byte EOF block)
+//   BAM  : SAMv1 section 4.2 (header, records, aux fields)
+// What the reference does with htslib at this boundary: src/corelib/sam_batch.hpp:12-54 (reader, 8 threads),
+// src/app/hifimeth/mod_main.cpp:316-362 (writer), src/corelib/build_mod_bam.cpp:87-248 (tags).
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/hifimeth_hip.h"
+
+namespace hmbam {
+
+class BgzfReader {
+public:
+    BgzfReader(const std::string& path, int threads);
+    ~BgzfReader();
+    bool ok() const { return fp_ != nullptr && err_.empty(); }
+    const std::string& error() const { return err_; }
+    // read exactly n bytes; returns false at clean EOF (0 bytes available) or on error (error() set)
+    bool read(void* dst, size_t n);
+
+private:
+    bool refill();
+    FILE* fp_ = nullptr;
+    int threads_;
+    std::vector<uint8_t> buf_;
+    size_t pos_ = 0;
+    bool eof_ = false;
+    std::string err_;
+};
+
+class BgzfWriter {
+public:
+    BgzfWriter(const std::string& path, int threads, int level);
+    ~BgzfWriter();
+    bool ok() const { return fp_ != nullptr && err_.empty(); }
+    const std::string& error() const { return err_; }
+    void write(const void* src, size_t n);
+    bool close();  // flushes and appends the EOF marker block
+
+private:
+    void flush_blocks(bool all);
+    FILE* fp_ = nullptr;
+    int threads_, level_;
+    std::vector<uint8_t> buf_;
+    std::string err_;
+};
+
+struct BamHeader {
+    std::string text;
+    std::vector<std::pair<std::string, int32_t>> refs;
+};
+
+// One BAM record: `data` holds everything after the 4-byte block_size.
+struct BamRecord {
+    std::vector<uint8_t> data;
+    int32_t l_qseq() const;
+    uint16_t flag() const;
+    int l_read_name() const { return data[8]; }
+    int n_cigar() const;
+    const uint8_t* seq4() const;
+    size_t aux_offset() const;
+};
+
+struct AuxField {
+    char tag[2];
+    char type;
+    char subtype;           // for 'B'
+    uint32_t count;         // for 'B'
+    const uint8_t* payload; // first data byte ('B': first element)
+    size_t total;           // bytes of the whole field incl. tag and type
+};
+
+// walks the aux block; returns false (and stops) on a corrupt field
+bool next_aux(const uint8_t*& p, const uint8_t* end, AuxField& f);
+
+bool read_header(BgzfReader& in, BamHeader& h, std::string& err);
+void write_header(BgzfWriter& out, const BamHeader& h);
+bool read_record(BgzfReader& in, BamRecord& r, std::string& err);
+void write_record(BgzfWriter& out, const BamRecord& r);
+
+// Kinetics views of a record for hm_submit_read: NULL when the tag is missing, not a B:C / B:S array or has the
+// wrong length (BamKinetics::init, bam_info.cpp:443-453,572-603).
+struct KineticsView {
+    const void* arr[4];  // fi, fp, ri, rp
+    int width[4];
+};
+KineticsView kinetics_of(const BamRecord& r);
+
+// forward-strand base of forward position k (BamQuerySequence::get_bam_fwd_strand_base, bam_info.cpp:224-233)
+char fwd_strand_base(const BamRecord& r, int k);
+
+// build_one_mod_bam (build_mod_bam.cpp:125-248): strips fi/ri/fp/rp (unless keep_kinetics) and any old MM/ML,
+// then -- if there is at least one call -- appends MM:Z, ML:B:C and MN.  `calls` are this read's calls in the
+// order hm_fetch returns them: FWD strand ascending qoff, then REV strand ascending qoff.
+// Returns false if a call does not sit on a C (FWD) / G (REV) or the per-strand order is not strictly increasing
+// (the reference hbn_assert()s these).
+bool apply_calls(BamRecord& r, const hm_call_t* calls, size_t n, bool keep_kinetics, std::string& err);
+
+}  // namespace hmbam

@@ -1,0 +1,25 @@
+"""Restatement of the reference's MM/ML/MN tag builder (test infrastructure only).
+
+Follows src/corelib/build_mod_bam.cpp:125-248: MM:Z = "C+m" {",d"} ";" "G-m" {",d"} ";" where d is the number of
+unmodified-candidate bases (C on the forward strand, resp. G) skipped since the previous call; ML:B:C = forward calls
+then reverse calls; MN = l_qseq.  `fwd_seq` is the forward-strand sequence (bam_info.cpp:224-233)."""
+import numpy as np
+
+
+def expected_tags(fwd_seq: bytes, qoff, strand, ml):
+    qoff, strand, ml = np.asarray(qoff), np.asarray(strand), np.asarray(ml, np.uint8)
+    if len(qoff) == 0:
+        return None
+    seq = np.frombuffer(fwd_seq, np.uint8)
+    parts, mls = [], []
+    for s, base, head in ((0, ord("C"), "C+m"), (1, ord("G"), "G-m")):
+        sel = np.nonzero(strand == s)[0]
+        sel = sel[np.argsort(qoff[sel], kind="stable")]
+        q = qoff[sel]
+        assert (np.diff(q) > 0).all() and (seq[q] == base).all()
+        is_b = np.concatenate([[0], np.cumsum(seq == base)])          # prefix count of candidate bases
+        last = np.concatenate([[0], q[:-1] + 1])
+        deltas = is_b[q] - is_b[last]
+        parts.append(head + "".join(f",{int(d)}" for d in deltas) + ";")
+        mls.append(ml[sel])
+    return dict(MM="".join(parts), ML=np.concatenate(mls), MN=len(fwd_seq))

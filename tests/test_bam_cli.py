@@ -1,0 +1,144 @@
+"""The BAM front end (`hifimeth-hip`): BGZF/BAM codec and the MM/ML/MN writer, on CPU (no GPU needed:
+sub-commands bamcopy / tagtest), against the restated reference tag builder (oracle/modtags.py)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from hifimeth_amd.caller import CALL_DTYPE
+from hifimeth_amd.synth import synth_reads
+
+import bamutil
+
+CLI = os.path.join(ROOT, "hifimeth_amd", "bin", "hifimeth-hip")
+
+
+def _reads():
+    return synth_reads(7, seed=3, median_len=1800, sigma=0.3, frac_wide=0.3, frac_short=0.2, frac_missing=0.2)
+
+
+def _oracle_calls(oracle, oracle_models, reads, mask=7):
+    recs = []
+    for i, rd in enumerate(reads):
+        if not rd.has_kinetics() or rd.l_qseq < 1000:
+            continue
+        r = oracle.call_read(oracle_models, mask, rd)
+        order = np.lexsort((r["qoff"], r["strand"]))
+        c = np.zeros(len(order), CALL_DTYPE)
+        c["read_id"], c["qoff"], c["strand"], c["ctx"] = i, r["qoff"][order], r["strand"][order], r["ctx"][order]
+        c["scaled_prob"], c["p"] = r["ml"][order], r["p"][order]
+        recs.append(c)
+    return np.concatenate(recs)
+
+
+def test_bamcopy_roundtrip(tmp_path):
+    reads = _reads()
+    src, dst = str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
+    bamutil.reads_to_bam(src, reads)
+    subprocess.check_call([CLI, "bamcopy", src, dst])
+    t0, r0 = bamutil.read_bam(src)
+    t1, r1 = bamutil.read_bam(dst)
+    assert t0 == t1 and len(r0) == len(r1) == len(reads)
+    assert all(a["raw"] == b["raw"] for a, b in zip(r0, r1))
+    # many blocks, multi-threaded inflate/deflate path: a larger file
+    big = synth_reads(40, seed=8, frac_missing=0)
+    bamutil.reads_to_bam(src, big)
+    subprocess.check_call([CLI, "bamcopy", src, dst])
+    assert [r["raw"] for r in bamutil.read_bam(src)[1]] == [r["raw"] for r in bamutil.read_bam(dst)[1]]
+    assert open(dst, "rb").read()[-28:] == bamutil._EOF
+
+
+def test_bad_input_is_rejected(tmp_path):
+    bad = tmp_path / "bad.bam"
+    bad.write_bytes(b"not a bam file at all")
+    assert subprocess.call([CLI, "bamcopy", str(bad), str(tmp_path / "o.bam")], stderr=subprocess.DEVNULL) != 0
+    assert subprocess.call([CLI, "call", "-c", "cpg,foo", "a.bam", "b.bam"], stderr=subprocess.DEVNULL) != 0
+    assert subprocess.call([CLI, "call", "only-one-arg.bam"], stderr=subprocess.DEVNULL) != 0
+
+
+@pytest.mark.parametrize("keep", [False, True])
+def test_tag_writer_matches_reference_rules(tmp_path, oracle, oracle_models, keep):
+    from oracle.modtags import expected_tags
+    reads = _reads()
+    calls = _oracle_calls(oracle, oracle_models, reads)
+    src, dst, cb = str(tmp_path / "in.bam"), str(tmp_path / "out.bam"), str(tmp_path / "calls.bin")
+    # records 0 and 1 carry stale MM/ML tags that must disappear
+    stale = lambda i, r: (bamutil.aux_Z("MM", "C+m,1;") + bamutil.aux_B("ML", np.array([7], np.uint8))) if i < 2 else b""
+    bamutil.reads_to_bam(src, reads, extra_aux=stale)
+    calls.tofile(cb)
+    subprocess.check_call([CLI, "tagtest", src, cb, dst] + (["-k"] if keep else []))
+    text, recs = bamutil.read_bam(dst)
+    assert "@PG\tID:hifimeth-hip" in text and text.startswith("@HD")
+    assert len(recs) == len(reads)
+    for i, (rd, rec) in enumerate(zip(reads, recs)):
+        assert rec["name"] == rd.name and rec["l_seq"] == rd.l_qseq and np.array_equal(rec["seq4"], rd.seq4)
+        tags = bamutil.parse_aux(rec["aux"])
+        names = [t[0] for t in tags]
+        assert names[:3] == ["np", "rq", "RG"] and "zm" in names          # untouched tags keep their order
+        for k in ("fi", "fp", "ri", "rp"):
+            present = getattr(rd, k) is not None
+            assert (k in names) == (keep and present)
+        mine = calls[calls["read_id"] == i]
+        want = expected_tags(oracle.decode(rd), mine["qoff"], mine["strand"], mine["scaled_prob"]) if len(mine) else None
+        d = {t[0]: t for t in tags}
+        if want is None:
+            assert "MM" not in d and "ML" not in d and "MN" not in d       # build_mod_bam.cpp:129-130 returns early
+            continue
+        assert names[-3:] == ["MM", "ML", "MN"]
+        assert d["MM"][1] == "Z" and d["MM"][2] == want["MM"]
+        assert d["ML"][1] == "BC" and np.array_equal(d["ML"][2], want["ML"])
+        assert d["MN"][2] == want["MN"] and d["MN"][1] == ("S" if rd.l_qseq <= 0xffff else "I")
+        assert names.count("MM") == 1 and names.count("ML") == 1
+
+
+def test_tag_writer_reverse_flag_read(tmp_path, oracle, oracle_models):
+    """flag 0x10: MM deltas count C/G on the FORWARD strand (get_bam_fwd_strand_base, bam_info.cpp:224-233)."""
+    from oracle.modtags import expected_tags
+    rd = synth_reads(1, seed=2, median_len=1300, sigma=0.05, frac_short=0, frac_missing=0, frac_wide=0)[0]
+    rd.flag = 16
+    calls = _oracle_calls(oracle, oracle_models, [rd], mask=1)
+    src, dst, cb = str(tmp_path / "in.bam"), str(tmp_path / "out.bam"), str(tmp_path / "calls.bin")
+    bamutil.reads_to_bam(src, [rd])
+    calls.tofile(cb)
+    subprocess.check_call([CLI, "tagtest", src, cb, dst])
+    tags = {t[0]: t for t in bamutil.parse_aux(bamutil.read_bam(dst)[1][0]["aux"])}
+    want = expected_tags(oracle.decode(rd), calls["qoff"], calls["strand"], calls["scaled_prob"])
+    assert tags["MM"][2] == want["MM"] and np.array_equal(tags["ML"][2], want["ML"])
+
+
+def test_tag_writer_rejects_unsorted_calls(tmp_path, oracle, oracle_models):
+    reads = _reads()
+    calls = _oracle_calls(oracle, oracle_models, reads)
+    calls[[0, 1]] = calls[[1, 0]]                                          # per-strand order violated
+    src, cb = str(tmp_path / "in.bam"), str(tmp_path / "calls.bin")
+    bamutil.reads_to_bam(src, reads)
+    calls.tofile(cb)
+    assert subprocess.call([CLI, "tagtest", src, cb, str(tmp_path / "o.bam")], stderr=subprocess.DEVNULL) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ctx,mask", [("cpg,chg,chh", 7), ("cpg", 1)])
+def test_cli_call_end_to_end(tmp_path, oracle, oracle_models, ctx, mask):
+    """hifimeth-hip call on a synthetic BAM; MM strings exact, ML within 1 LSB of the oracle's."""
+    from oracle.modtags import expected_tags
+    reads = synth_reads(25, seed=44, median_len=2500, sigma=0.4, frac_wide=0.1, frac_short=0.1, frac_missing=0.1)
+    src, dst = str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
+    bamutil.reads_to_bam(src, reads)
+    subprocess.check_call([CLI, "call", "-c", ctx, "-b", "7", "-t", "4", src, dst])   # small -b: several batches in flight
+    _, recs = bamutil.read_bam(dst)
+    assert [r["name"] for r in recs] == [r.name for r in reads]           # input order preserved
+    called = 0
+    for rd, rec in zip(reads, recs):
+        tags = {t[0]: t for t in bamutil.parse_aux(rec["aux"])}
+        assert not ({"fi", "fp", "ri", "rp"} & set(tags))
+        if not rd.has_kinetics() or rd.l_qseq < 1000:
+            assert "MM" not in tags
+            continue
+        r = oracle.call_read(oracle_models, mask, rd)
+        want = expected_tags(oracle.decode(rd), r["qoff"], r["strand"], r["ml"])
+        assert tags["MM"][2] == want["MM"] and tags["MN"][2] == rd.l_qseq
+        assert np.abs(tags["ML"][2].astype(int) - want["ML"].astype(int)).max() <= 1
+        called += 1
+    assert called >= 15
