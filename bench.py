@@ -98,13 +98,13 @@ def roofline(precision, achieved, front_ms, front_launches):
     # the committed summary of the last such pass is quoted, with its source, when present
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-        if precision == 1:
+        if precision >= 1:
             t = pmc["front_kernel_h<13> per launch (65536 sites)"]
             base["traffic"] = t["hbm_read_bytes_corrected"] + t["hbm_write_bytes"]
             base["traffic_source"] = "profiles/r01_pmc_summary.json (front_kernel_h<13>, 65536 sites per launch; FETCH_SIZE x2 corrected)"
     except (OSError, KeyError, ValueError):
         pass
-    if precision == 1:
+    if precision >= 1:
         base.update(kernel="front_kernel_h (window+bn0+conv1..conv4, v_mfma_f32_16x16x32_f16 x3 split-half, fp32 accumulate)",
                     peak=PEAK_FP16_MFMA_TFLOPS, frac=achieved / PEAK_FP16_MFMA_TFLOPS,
                     executed=3.0 * achieved, frac_executed=3.0 * achieved / PEAK_FP16_MFMA_TFLOPS,
@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=96, help="reads per GPU batch (~15 kb each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
+    ap.add_argument("--precision", type=int, default=1, choices=[0, 1, 2],
                     help="front-kernel arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (e.g. front_waves=8)")
     args = ap.parse_args()
@@ -193,7 +193,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16x3+f32acc" if args.precision == 1 else "f32",
+            "dtype": {0: "f32", 1: "f16x3+f32acc", 2: "f16w/f16x2+f32acc"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "synthetic 30x-style HiFi reads (GC 0.36, ~15 kb log-normal, codev1 kinetics), "
                                    "all three contexts, batch resident in HBM; BASELINE.json configs[2] statistics",

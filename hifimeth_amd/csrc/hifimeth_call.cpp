@@ -52,7 +52,8 @@ void usage() {
             "  -c <list>    contexts to call: cpg,chg,chh (default all)\n"
             "  -t <int>     host threads for BGZF inflate/deflate (default: all, max 16)\n"
             "  -d <list>    GPU ordinals, e.g. 0,1,2,3 (default 0)\n"
-            "  -p <0|1>     arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA\n"
+            "  -p <0|1|2>   arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA,\n"
+            "               2 = fp16 weights for conv2..conv8 (|dp| <= 1e-3 mode)\n"
             "  -z <0-9>     output compression level (default 6)\n",
             kName);
 }
@@ -128,7 +129,7 @@ bool parse(int argc, char** argv, Options& o) {
     o.out = argv[i + 1];
     if (o.model_dir.empty()) o.model_dir = exe_dir() + "/../weights";
     if (o.threads <= 0) o.threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (o.read_batch < 1 || o.min_read_size < 0 || o.level < 0 || o.level > 9 || (o.precision != 0 && o.precision != 1)) return false;
+    if (o.read_batch < 1 || o.min_read_size < 0 || o.level < 0 || o.level > 9 || o.precision < 0 || o.precision > 2) return false;
     return true;
 }
 

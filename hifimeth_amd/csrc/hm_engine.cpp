@@ -243,10 +243,10 @@ void run_cnn(hm_engine* e, int ctx, const Site* sites, const float* windows, int
         const float* w_off = windows ? windows + (size_t)off * KMER * FEATS : nullptr;
         {
             Span sp(e, K_FRONT0 + ctx, m);
-            if (e->precision == 1)
+            if (e->precision >= 1)
                 launch_front_h(e->stream, dm.k1, s_off, m, e->d_reads.as<ReadDesc>(), e->d_bases.as<uint8_t>(),
                                e->d_kin.as<uint32_t>(), w_off, dm.w, e->d_act4.as<float>(), e->num_cu, dbg, dbg_layer,
-                               e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr);
+                               e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr, e->precision == 2);
             else
                 launch_front(e->stream, dm.k1, s_off, m, e->d_reads.as<ReadDesc>(), e->d_bases.as<uint8_t>(),
                              e->d_kin.as<uint32_t>(), w_off, dm.w, e->d_act4.as<float>(), e->num_cu, dbg, dbg_layer,
@@ -260,8 +260,9 @@ void run_cnn(hm_engine* e, int ctx, const Site* sites, const float* windows, int
             float* lg = e->d_logits.as<float>() + (sites ? 0 : 2 * off);
             float* pp = e->d_p.as<float>() + (sites ? 0 : off);
             uint8_t* mm = e->d_ml.as<uint8_t>() + (sites ? 0 : off);
-            if (e->precision == 1)
-                launch_tail_h(e->stream, e->d_act4.as<float>(), m, dm.w, s_off, lg, pp, mm, e->num_cu, dbg, dbg_layer);
+            if (e->precision >= 1)
+                launch_tail_h(e->stream, e->d_act4.as<float>(), m, dm.w, s_off, lg, pp, mm, e->num_cu, dbg, dbg_layer,
+                              e->precision == 2);
             else
                 launch_tail(e->stream, e->d_act4.as<float>(), m, dm.w, s_off, lg, pp, mm, e->num_cu, dbg, dbg_layer);
             sp.end();
@@ -348,7 +349,7 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
     if (k == "min_read_size") e->min_read_size = (int)value;
     else if (k == "timing") e->timing = value != 0;
     else if (k == "precision") {
-        if (value != 0 && value != 1) return fail(e, HM_EINVAL, "precision must be 0 (fp32) or 1 (f16x3 split)");
+        if (value < 0 || value > 2) return fail(e, HM_EINVAL, "precision must be 0 (fp32), 1 (f16x3 split) or 2 (fp16 weights)");
         e->precision = (int)value;
     } else if (k == "stamps") {
         e->stamps_on = value != 0;

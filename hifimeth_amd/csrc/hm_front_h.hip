@@ -38,8 +38,9 @@ __device__ __forceinline__ void split4(const f32x4& v, half4& hi, half4& lo) {
 //   CIN >= 32 : channels c0 + 8*lk .. +7 of tap (32*kb)/CIN          (a block never straddles taps)
 //   CIN == 8  : all 8 channels of tap 4*kb + lk
 // S sites may be stacked along M (tail kernel): row m -> (site = m / LOUT, p = m % LOUT), site stride ISS halves.
+// WLO = false drops the w_lo*x_hi pass: the layer then runs with plain fp16 WEIGHTS (BASELINE.json configs[4]).
 template <int NW_, int CIN_, int KT_, int COUT_, int LOUT_, int IRS_, int WM_, int WN_, int BR_ = 2, int S_ = 1,
-          int ISS_ = 0, int ROW0_ = 0>
+          int ISS_ = 0, int ROW0_ = 0, bool WLO = true>
 struct ConvH {
     static constexpr int NW = NW_, CIN = CIN_, KT = KT_, COUT = COUT_, LOUT = LOUT_, IRS = IRS_, WM = WM_, WN = WN_, BR = BR_;
     static constexpr int S = S_, ISS = ISS_, ROW0 = ROW0_;
@@ -96,7 +97,7 @@ struct ConvH {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 wq[r][j][0] = wp[(size_t)(j * KB + r) * 128];
-                wq[r][j][1] = wp[(size_t)(j * KB + r) * 128 + 64];
+                if (WLO) wq[r][j][1] = wp[(size_t)(j * KB + r) * 128 + 64];
             }
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
@@ -112,7 +113,7 @@ struct ConvH {
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
                     wq[(RB + BR - 1) % BR][j][0] = wp[(size_t)(j * KB + kw) * 128];
-                    wq[(RB + BR - 1) % BR][j][1] = wp[(size_t)(j * KB + kw) * 128 + 64];
+                    if (WLO) wq[(RB + BR - 1) % BR][j][1] = wp[(size_t)(j * KB + kw) * 128 + 64];
                 }
             }
             {
@@ -129,7 +130,7 @@ struct ConvH {
             // the three partial products, outermost so that an accumulator is revisited only after
             // MTW*NTW other MFMAs (no back-to-back dependent MFMAs)
 #pragma unroll
-            for (int pr = 0; pr < 3; ++pr)
+            for (int pr = 0; pr < (WLO ? 3 : 2); ++pr)
 #pragma unroll
                 for (int i = 0; i < MTW; ++i)
 #pragma unroll
@@ -243,7 +244,7 @@ __device__ __forceinline__ void dump_planes(const half_t* hi, const half_t* lo, 
     }
 }
 
-template <int K1, bool RAW, bool STAMP = false>
+template <int K1, bool RAW, bool STAMP = false, bool W16 = false>
 __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ sites, int n_sites,
                                                        const ReadDesc* __restrict__ reads,
                                                        const uint8_t* __restrict__ bases,
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         if (dbg && dbg_layer == 1 && s == 0) dump_planes<G::L1, 128, G::RS>(a_hi, a_lo, dbg);
 
         // conv2: planes A -> planes B
-        ConvH<NW, 128, 3, 128, G::L2, G::RS, 1, 8, 3>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]),
+        ConvH<NW, 128, 3, 128, G::L2, G::RS, 1, 8, 3, 1, 0, 0, !W16>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]),
                                                            EpiPlanes<G::RS>{b_hi, b_lo, W.bias[1]});
         mk(8);
         zero_rows_h<128>(b_hi, b_lo, 0, G::L2 + 1, G::RS);
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         if (dbg && dbg_layer == 2 && s == 0) dump_planes<G::L2, 128, G::RS>(b_hi, b_lo, dbg);
 
         // conv3: planes B -> planes A
-        ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 4>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
+        ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 4, 1, 0, 0, !W16>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
                                                            EpiPlanes<G::RS>{a_hi, a_lo, W.bias[2]});
         mk(12);
         zero_rows_h<128>(a_hi, a_lo, 0, G::L3 + 1, G::RS);
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
 
         // conv4: planes A -> act4[s] (fp32, hand-off to the tail kernel) on 6 waves (one 16-channel tile column
         // each, weights 5 k-blocks ahead); the other 2 build the next site's window in planes B meanwhile
-        ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 6>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]),
+        ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 6, 1, 0, 0, !W16>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]),
                                                             EpiGlobalF<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]});
         mk(16);
         const int sn = s + gridDim.x;
@@ -437,6 +438,7 @@ __device__ __forceinline__ void zero_pad_rows_h(half_t* hi, half_t* lo, int rs, 
     }
 }
 
+template <bool W16>
 __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ act4, int n_sites, CtxWeights W,
                                                       const Site* __restrict__ sites, float* __restrict__ logits,
                                                       float* __restrict__ prob, uint8_t* __restrict__ ml,
@@ -469,25 +471,25 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         zero_pad_rows_h<S, T::L4, 96>(h0, l0, T::RS96, T::IN_SS);
         __syncthreads();
 
-        ConvH<NW, 96, 3, 96, T::L5, T::RS96, 4, 2, 3, S, T::IN_SS, 0>::run(
+        ConvH<NW, 96, 3, 96, T::L5, T::RS96, 4, 2, 3, S, T::IN_SS, 0, !W16>::run(
             h0, l0, wf(4), EpiPlanesS<T::L5, T::RS96, T::C5_SS>{h1, l1, W.bias[4]});
         zero_pad_rows_h<S, T::L5, 96>(h1, l1, T::RS96, T::C5_SS);
         __syncthreads();
         if (dbg && dbg_layer == 5 && g == 0) dump_planes<T::L5, 96, T::RS96>(h1, l1, dbg);
 
-        ConvH<NW, 96, 3, 96, T::L6, T::RS96, 4, 2, 3, S, T::C5_SS, 0>::run(
+        ConvH<NW, 96, 3, 96, T::L6, T::RS96, 4, 2, 3, S, T::C5_SS, 0, !W16>::run(
             h1, l1, wf(5), EpiPlanesS<T::L6, T::RS96, T::C6_SS>{h0, l0, W.bias[5]});
         zero_pad_rows_h<S, T::L6, 96>(h0, l0, T::RS96, T::C6_SS);
         __syncthreads();
         if (dbg && dbg_layer == 6 && g == 0) dump_planes<T::L6, 96, T::RS96>(h0, l0, dbg);
 
-        ConvH<NW, 96, 3, 64, T::L7, T::RS96, 2, 4, 3, S, T::C6_SS, 0>::run(
+        ConvH<NW, 96, 3, 64, T::L7, T::RS96, 2, 4, 3, S, T::C6_SS, 0, !W16>::run(
             h0, l0, wf(6), EpiPlanesS<T::L7, T::RS64, T::C7_SS>{h1, l1, W.bias[6]});
         zero_pad_rows_h<S, T::L7, 64>(h1, l1, T::RS64, T::C7_SS);
         __syncthreads();
         if (dbg && dbg_layer == 7 && g == 0) dump_planes<T::L7, 64, T::RS64>(h1, l1, dbg);
 
-        ConvH<NW, 64, 3, 64, T::L8, T::RS64, 1, 4, 3, S, T::C7_SS, 0>::run(
+        ConvH<NW, 64, 3, 64, T::L8, T::RS64, 1, 4, 3, S, T::C7_SS, 0, !W16>::run(
             h1, l1, wf(7), EpiPlanesS<T::L8, T::RS64, T::C8_SS>{h0, l0, W.bias[7]});
         __syncthreads();
         if (dbg && dbg_layer == 8 && g == 0) dump_planes<T::L8, 64, T::RS64>(h0, l0, dbg);
@@ -528,19 +530,33 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
 }
 
 void launch_tail_h(hipStream_t st, const float* act4, int n, const CtxWeights& w, const Site* sites, float* logits,
-                   float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer) {
+                   float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer, bool w16) {
     if (n <= 0) return;
     const int groups = (n + TAIL_SITES - 1) / TAIL_SITES;
-    hipLaunchKernelGGL(tail_kernel_h, dim3(min(groups, grid)), dim3(512), 0, st, act4, n, w, sites, logits, p, ml, dbg,
-                       dbg_layer);
+    if (w16)
+        hipLaunchKernelGGL(tail_kernel_h<true>, dim3(min(groups, grid)), dim3(512), 0, st, act4, n, w, sites, logits, p, ml,
+                           dbg, dbg_layer);
+    else
+        hipLaunchKernelGGL(tail_kernel_h<false>, dim3(min(groups, grid)), dim3(512), 0, st, act4, n, w, sites, logits, p, ml,
+                           dbg, dbg_layer);
 }
 
 void launch_front_h(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
                     const uint32_t* kin, const float* windows, const CtxWeights& w, float* act4, int grid, float* dbg,
-                    int dbg_layer, unsigned long long* stamps) {
+                    int dbg_layer, unsigned long long* stamps, bool w16) {
     if (n <= 0) return;
     const dim3 g(min(n, grid)), b(512);
     const bool raw = windows == nullptr;
+    if (w16) {  // fp16-weights mode (conv1 and fc1 keep split weights): BASELINE.json configs[4]
+        if (k1 == 11) {
+            if (raw) hipLaunchKernelGGL((front_kernel_h<11, true, false, true>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
+            else hipLaunchKernelGGL((front_kernel_h<11, false, false, true>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
+        } else {
+            if (raw) hipLaunchKernelGGL((front_kernel_h<13, true, false, true>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
+            else hipLaunchKernelGGL((front_kernel_h<13, false, false, true>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
+        }
+        return;
+    }
 #define HM_FRONT_H(K1, RAW, ST)                                                                                       \
     hipLaunchKernelGGL((front_kernel_h<K1, RAW, ST>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, \
                        dbg_layer, stamps)

@@ -31,9 +31,9 @@ int front_stamp_slots();
 // split-half (f16x3) variant of the front kernel: fp16 hi/lo operands on v_mfma_f32_16x16x32_f16, fp32 accumulate
 void launch_front_h(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
                     const uint32_t* kin, const float* windows, const CtxWeights& w, float* act4, int grid, float* dbg,
-                    int dbg_layer, unsigned long long* stamps);
+                    int dbg_layer, unsigned long long* stamps, bool w16);
 void launch_tail_h(hipStream_t st, const float* act4, int n, const CtxWeights& w, const Site* sites, float* logits,
-                   float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer);
+                   float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer, bool w16);
 // tail: conv5..conv8, fc1, fc2, softmax for 8 sites per workgroup pass.
 // results go to index sites[i].uidx (or i when sites == nullptr).
 void launch_tail(hipStream_t st, const float* act4, int n, const CtxWeights& w, const Site* sites, float* logits,

@@ -75,7 +75,8 @@ void hm_destroy(hm_engine_t* e);
 const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a failed hm_create */
 /* options: "min_read_size" (-l, default 1000), "timing" (0/1), "sub_batch_sites" (front/tail
  * launch granularity, default 65536), "front_waves" (4 or 8 waves per front workgroup), "precision" (0 = fp32 MFMA, exact;
- * 1 = split-half fp16x3 MFMA with fp32 accumulate for conv1..conv4), "stamps" (diagnostic) */
+ * 1 = split-half fp16x3 MFMA with fp32 accumulate; 2 = fp16 WEIGHTS for conv2..conv8 (conv1 and fc1 keep split
+ * weights), activations still split, fp32 accumulate: BASELINE.json configs[4], bar |dp| <= 1e-3), "stamps" (diagnostic) */
 int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
 
 /* ---- staging: the EvalKmerFeaturesGenerator::init seam ----------------------------------- */
