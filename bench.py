@@ -174,6 +174,28 @@ def main():
     sites_all, dt_max = hmdist.job_throughput(dist, sites_step, dt, device="cuda" if on_gpu_collectives else "cpu")
 
     gpu_calls = mc.fetch() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+
+    # feature extraction measured standalone (outside the timed region): the materialised 401x8 fp32 windows of
+    # the largest context, device only.  In the product path the window never leaves LDS; this is the HBM-bound
+    # kernel the north-star asks to be priced against the HBM roofline.
+    feat = None
+    if rank == 0:
+        big = int(np.argmax(sites_ctx))
+        mc.timing(reset=True)
+        for _ in range(3):
+            mc.windows(big, 0, sites_ctx[big], fetch=False)
+        tw = mc.timing()
+        if tw["window_ms"] > 0:
+            wbytes = tw["window_sites"] * (401 * 8 * 4 + 401 * 5 + 12)   # window out + raw slice in + site record
+            feat = {"kernel": "window_kernel (401x8 fp32 windows to HBM, test/roofline seam)", "bound": "hbm",
+                    "achieved": wbytes / (tw["window_ms"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "sites_per_launch": sites_ctx[big], "avg_launch_ms": tw["window_ms"] / tw["window_launches"],
+                    "algorithmic_bytes_per_site": 401 * 8 * 4 + 401 * 5 + 12}
+            feat["frac"] = feat["achieved"] / feat["peak"]
+            prep_b = bases * (4.5 + 1 + 4) + sites_step * 21 + bases            # raw in, packed out, site records, emit re-read
+            feat["scan_kernels"] = {"prep_scan_emit_ms_per_step": (tm["prep_ms"] + tm["scan_ms"] + tm["emit_ms"]) / max(1, args.steps),
+                                    "achieved_GBps": prep_b / ((tm["prep_ms"] + tm["scan_ms"] + tm["emit_ms"]) / max(1, args.steps) * 1e-3) / 1e9,
+                                    "note": "launch-latency sized at this batch (1.5 Mbases): three launches of 5-20 us"}
     if rank == 0:
         front_ms = sum(tm["front_ms"])
         front_launches = sum(tm["front_launches"])
@@ -201,6 +223,7 @@ def main():
                        "sites_by_context": {"CpG": sites_ctx[0], "CHG": sites_ctx[1], "CHH": sites_ctx[2]},
                        "parallelism": f"read-sharded x{world}, no collective"},
             "roofline": roofline(args.precision, achieved, front_ms, front_launches),
+            "feature_extraction": feat,
             "device_ms_timed_region": gpu_ms,
             "effective_tflops_all_layers": sum(2.0 * MAC_TOTAL[c] * sites_ctx[c] for c in range(3)) * args.steps / dt_max / 1e12,
         }

@@ -105,9 +105,17 @@ struct ConvH {
             x[0][i][1] = *reinterpret_cast<const half8*>(in_lo + aoff[i]);
         }
 
+        // Two waves share each SIMD's matrix pipe; with equal priorities the older wave wins every arbitration,
+        // finishes its k-loop early and idles at the barrier while the younger one runs on alone at a lower issue
+        // rate.  Alternating the priority every k-block between the two halves of the workgroup keeps them level.
+        [[maybe_unused]] const bool upper_half = NW == 8 && wave >= 4;
         auto block = [&](auto rb_tag, auto ra_tag, const int kb) __attribute__((always_inline)) {
             constexpr int RB = decltype(rb_tag)::value;
             constexpr int RA = decltype(ra_tag)::value;
+#ifdef HM_PRIO_ALTERNATE
+            if (upper_half == (RA == 0)) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+#endif
             {
                 const int kw = kb + BR - 1 < KB ? kb + BR - 1 : KB - 1;
 #pragma unroll

@@ -12,6 +12,7 @@
 #include "hm_kernels.h"
 #include "hm_stamp.h"
 
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 
@@ -269,36 +270,40 @@ __global__ __launch_bounds__(PREP_THREADS) void emit_kernel(const ReadDesc* __re
     }
 }
 
-// one 401x8 window per workgroup pass, written as 802 coalesced float4 (12 832 B / site)
+// materialised 401x8 fp32 windows: one thread per window ROW (32 contiguous bytes), rows of consecutive sites
+// back to back, so a wave writes 2 KB contiguous; the 1 KB decode table sits in LDS (12 832 B / site out).
+// (One float4 per lane -- perfectly contiguous wave stores, but twice the index arithmetic -- measured slower:
+//  3.4 vs 4.5 TB/s.)
 __global__ __launch_bounds__(256) void window_kernel(const Site* __restrict__ sites, int n,
                                                       const ReadDesc* __restrict__ reads,
                                                       const uint8_t* __restrict__ bases,
                                                       const uint32_t* __restrict__ kin,
                                                       const BnTables* __restrict__ bn, float* __restrict__ out) {
-    for (int s = blockIdx.x; s < n; s += gridDim.x) {
+    __shared__ float lut[256];
+    lut[threadIdx.x] = bn->raw_lut[threadIdx.x];
+    __syncthreads();
+    const int64_t total = (int64_t)n * KMER;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+        const int s = (int)(g / KMER), r = (int)(g - (int64_t)s * KMER);
         const Site st = sites[s];
         const int L = reads[st.read_idx].len;
         const int64_t bo = reads[st.read_idx].base_off;
         const int rev = bases[bo + st.qoff] == 2;
-        float4* dst = reinterpret_cast<float4*>(out + (size_t)s * (KMER * FEATS));
-        for (int q = threadIdx.x; q < KMER * 2; q += 256) {
-            const int r = q >> 1;
-            const int j = rev ? st.qoff + HK - r : st.qoff - HK + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j >= 0 && j < L) {
-                if (!(q & 1)) {
-                    int b = bases[bo + j];
-                    if (rev && b < 4) b = 3 - b;
-                    v = make_float4(b == 0 ? 1.f : 0.f, b == 1 ? 1.f : 0.f, b == 2 ? 1.f : 0.f, b == 3 ? 1.f : 0.f);
-                } else {
-                    uint32_t k = kin[bo + j];
-                    if (rev) k = (k >> 16) | (k << 16);  // own strand first: (ri, rp, fi, fp)
-                    v = make_float4(bn->raw_lut[k & 255], bn->raw_lut[(k >> 8) & 255], bn->raw_lut[(k >> 16) & 255],
-                                    bn->raw_lut[k >> 24]);
-                }
+        const int j = rev ? st.qoff + HK - r : st.qoff - HK + r;
+        float4 hot = make_float4(0.f, 0.f, 0.f, 0.f), kv = hot;
+        if (j >= 0 && j < L) {
+            int b = bases[bo + j];
+            uint32_t k = kin[bo + j];
+            if (rev) {
+                if (b < 4) b = 3 - b;
+                k = (k >> 16) | (k << 16);  // own strand first: (ri, rp, fi, fp)
             }
-            dst[q] = v;
+            hot = make_float4(b == 0 ? 1.f : 0.f, b == 1 ? 1.f : 0.f, b == 2 ? 1.f : 0.f, b == 3 ? 1.f : 0.f);
+            kv = make_float4(lut[k & 255], lut[(k >> 8) & 255], lut[(k >> 16) & 255], lut[k >> 24]);
         }
+        float4* dst = reinterpret_cast<float4*>(out + g * FEATS);
+        dst[0] = hot;
+        dst[1] = kv;
     }
 }
 
@@ -887,7 +892,9 @@ void launch_emit(hipStream_t st, const ReadDesc* reads, const Chunk* chunks, int
 void launch_windows(hipStream_t st, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
                     const uint32_t* kin, const BnTables* bn, float* out, int grid) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(window_kernel, dim3(min(n, grid)), dim3(256), 0, st, sites, n, reads, bases, kin, bn, out);
+    const int64_t blocks = ((int64_t)n * KMER + 255) / 256;
+    hipLaunchKernelGGL(window_kernel, dim3((unsigned)std::min<int64_t>(blocks, grid)), dim3(256), 0, st, sites, n, reads,
+                       bases, kin, bn, out);
 }
 
 void launch_front(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
