@@ -105,17 +105,9 @@ struct ConvH {
             x[0][i][1] = *reinterpret_cast<const half8*>(in_lo + aoff[i]);
         }
 
-        // Two waves share each SIMD's matrix pipe; with equal priorities the older wave wins every arbitration,
-        // finishes its k-loop early and idles at the barrier while the younger one runs on alone at a lower issue
-        // rate.  Alternating the priority every k-block between the two halves of the workgroup keeps them level.
-        [[maybe_unused]] const bool upper_half = NW == 8 && wave >= 4;
         auto block = [&](auto rb_tag, auto ra_tag, const int kb) __attribute__((always_inline)) {
             constexpr int RB = decltype(rb_tag)::value;
             constexpr int RA = decltype(ra_tag)::value;
-#ifdef HM_PRIO_ALTERNATE
-            if (upper_half == (RA == 0)) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-#endif
             {
                 const int kw = kb + BR - 1 < KB ? kb + BR - 1 : KB - 1;
 #pragma unroll
@@ -132,9 +124,7 @@ struct ConvH {
                     x[RA ^ 1][i][1] = *reinterpret_cast<const half8*>(in_lo + bo + aoff[i]);
                 }
             }
-#if !defined(HM_H_SCHED) || HM_H_SCHED == 0
             __builtin_amdgcn_sched_barrier(0);
-#endif
             // the three partial products, outermost so that an accumulator is revisited only after
             // MTW*NTW other MFMAs (no back-to-back dependent MFMAs)
 #pragma unroll
@@ -145,26 +135,6 @@ struct ConvH {
                     for (int j = 0; j < NTW; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[RB][j][pr == 2 ? 1 : 0], x[RA][i][pr == 1 ? 1 : 0],
                                                                            acc[i][j], 0, 0, 0);
-#if defined(HM_H_SCHED) && HM_H_SCHED == 2
-            // one load (VMEM or LDS, with its address VALU) in the shadow of every MPS MFMAs
-            {
-                constexpr int NM = 3 * MTW * NTW, NL = 2 * NTW + 2 * MTW;
-                constexpr int MPS = NM / NL > 0 ? NM / NL : 1;
-#pragma unroll
-                for (int t = 0; t < 2 * NTW; ++t) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, MPS, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-#pragma unroll
-                for (int t = 0; t < 2 * MTW; ++t) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, MPS, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-            }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         constexpr int UN = BR % 2 == 0 ? BR : 2 * BR;

@@ -412,12 +412,6 @@ struct Conv {
         float4 bq[BR][NTW];
         float4 a[2][MTW];
         // prologue: BR-1 k-groups of B and one k-group of A in flight
-#if defined(HM_ABL_NOB) || defined(HM_ABL_NOA)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) bq[BR - 1][j] = wp[(size_t)(j * KG) * 64];
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) a[1][i] = *reinterpret_cast<const float4*>(in + aoff[i]);
-#endif
 #pragma unroll
         for (int r = 0; r < BR - 1; ++r)
 #pragma unroll
@@ -437,23 +431,17 @@ struct Conv {
 #pragma unroll
                 for (int r = 0; r < VRN; ++r) ar[r] = *reinterpret_cast<const float4*>(gc + roff[r]);
             }
-#ifndef HM_ABL_NOB
             {
                 const int kb = kg + BR - 1 < KG ? kg + BR - 1 : KG - 1;
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) bq[(RB + BR - 1) % BR][j] = wp[(size_t)(j * KG + kb) * 64];
             }
-#endif
-#ifndef HM_ABL_NOA
             {
                 const float* gn = in + group_off(kg + 1 < KG ? kg + 1 : KG - 1);
 #pragma unroll
                 for (int i = 0; i < MTW; ++i) a[RA ^ 1][i] = *reinterpret_cast<const float4*>(gn + aoff[i]);
             }
-#endif
-#ifndef HM_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);  // loads first, then the MFMA block (measured faster than interleaving)
-#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -477,40 +465,6 @@ struct Conv {
                         psum[r][j] = t;
                     }
             }
-#ifdef HM_INTERLEAVE
-            // Issue order inside the group: every non-MFMA instruction goes into the shadow of an MFMA (an MFMA
-            // occupies the matrix pipe for 32 cycles but the issue port only briefly), instead of a block of
-            // loads in front of a block of MFMAs: VALU-row reads first (their FMAs come last), then the B and A
-            // prefetches, then the FMAs.
-            constexpr int NM = 4 * MTW * NTW;
-            constexpr int NVR = VR > 0 ? VR : 0;
-            constexpr int NSLOT = NVR + NTW + MTW + NVR * NTW;  // interleave points
-            constexpr int MPS = NM / NSLOT > 0 ? NM / NSLOT : 1;  // MFMAs per interleave point
-#pragma unroll
-            for (int t = 0; t < NVR; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, MPS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, MPS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < MTW; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, MPS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < NVR * NTW; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, MPS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);  // whatever MFMAs are left
-#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         mark(0);
@@ -702,10 +656,6 @@ __global__ __launch_bounds__(NW * 64) void front_kernel(const Site* __restrict__
     constexpr int C4_WAVES = 4;
     constexpr bool SPARE = NW > C4_WAVES;
 
-#ifdef HM_EXP_PRIO
-    // static priority for the younger half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-    if (NW == 8 && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
-#endif
     if ((int)blockIdx.x < n_sites) build_window(blockIdx.x, threadIdx.x, NW * 64);
     for (int s = blockIdx.x; s < n_sites; s += gridDim.x) {
         if (STAMP) tprev = hm_stamp();
