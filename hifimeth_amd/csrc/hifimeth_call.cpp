@@ -6,6 +6,7 @@
 // Two extra sub-commands need no GPU and exist for the CPU test-suite:
 //     hifimeth-hip bamcopy IN.bam OUT.bam             (BGZF/BAM round trip)
 //     hifimeth-hip tagtest IN.bam CALLS.bin OUT.bam   (apply hm_call_t records, read_id = record index)
+//     hifimeth-hip modstats IN.bam                    (MM/ML parser + per-context histograms + adaptive thresholds)
 #include <unistd.h>
 
 #include <algorithm>
@@ -296,6 +297,49 @@ int cmd_tagtest(int argc, char** argv) {
     return out.close() ? 0 : EXIT_FAILURE;
 }
 
+// modstats IN.bam : the alignment-free first pass of `hifimeth pileup` (src/app/hifimeth/pileup.cpp:237-272,355-436):
+// parse MM/ML, histogram the 5mC probabilities of primary reads per context, resolve the adaptive thresholds.
+// Prints one JSON object.
+int cmd_modstats(int argc, char** argv) {
+    if (argc != 3) { usage(); return EXIT_FAILURE; }
+    BgzfReader in(argv[2], 8);
+    BamHeader h;
+    std::string err;
+    if (!in.ok() || !read_header(in, h, err)) { fprintf(stderr, "%s%s\n", in.error().c_str(), err.c_str()); return EXIT_FAILURE; }
+    static uint64_t bins[3][256];
+    memset(bins, 0, sizeof bins);
+    BamRecord r;
+    std::vector<BaseMod> mods;
+    uint64_t reads = 0, with_mods = 0, calls = 0;
+    while (read_record(in, r, err)) {
+        ++reads;
+        if (!parse_mods(r, mods, err)) { fprintf(stderr, "read %llu: %s\n", (unsigned long long)reads - 1, err.c_str()); return EXIT_FAILURE; }
+        if (mods.empty()) continue;
+        ++with_mods;
+        if (r.flag() & 0x900) continue;  // primary records only (pileup.cpp:237)
+        for (const BaseMod& m : mods) {
+            if (m.unmod_base != 'C' && m.unmod_base != 'G') continue;
+            const int c = mod_context(r, m.qoff);
+            if (c < 0) continue;
+            ++bins[c][m.prob];
+            ++calls;
+        }
+    }
+    if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return EXIT_FAILURE; }
+    static const char* cn[3] = {"CpG", "CHG", "CHH"};
+    printf("{\"reads\": %llu, \"reads_with_mods\": %llu, \"calls\": %llu", (unsigned long long)reads,
+           (unsigned long long)with_mods, (unsigned long long)calls);
+    for (int c = 0; c < 3; ++c) {
+        uint64_t n = 0;
+        const int thr = resolve_threshold(bins[c], &n);
+        printf(", \"%s\": {\"threshold\": %d, \"samples_in_window\": %llu, \"bins\": [", cn[c], thr, (unsigned long long)n);
+        for (int i = 0; i < 256; ++i) printf("%s%llu", i ? "," : "", (unsigned long long)bins[c][i]);
+        printf("]}");
+    }
+    printf("}\n");
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -304,6 +348,7 @@ int main(int argc, char** argv) {
     if (cmd == "call") return cmd_call(argc, argv);
     if (cmd == "bamcopy") return cmd_bamcopy(argc, argv);
     if (cmd == "tagtest") return cmd_tagtest(argc, argv);
+    if (cmd == "modstats") return cmd_modstats(argc, argv);
     usage();
     return EXIT_FAILURE;
 }

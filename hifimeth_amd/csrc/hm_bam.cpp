@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cstring>
 #include <thread>
 
@@ -455,6 +456,139 @@ bool apply_calls(BamRecord& r, const hm_call_t* calls, size_t n, bool keep_kinet
     r.data.resize(aux0);
     r.data.insert(r.data.end(), aux.begin(), aux.end());
     return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MM/ML parser, contexts, thresholds
+// ------------------------------------------------------------------------------------------------
+static char chebi_to_code(long c) {  // bam_mod_parser.cpp:36-77
+    switch (c) {
+    case 27551: return 'm';
+    case 76792: return 'h';
+    case 76794: return 'f';
+    case 76793: return 'c';
+    case 16964: return 'g';
+    case 80961: return 'e';
+    case 17477: return 'b';
+    case 28871: return 'a';
+    case 44605: return 'o';
+    case 18107: return 'n';
+    default: return 0;
+    }
+}
+
+bool parse_mods(const BamRecord& r, std::vector<BaseMod>& mods, std::string& err) {
+    mods.clear();
+    const uint8_t* p = r.data.data() + r.aux_offset();
+    const uint8_t* end = r.data.data() + r.data.size();
+    AuxField f, mm{}, ml{};
+    bool has_mm = false, has_ml = false;
+    while (p < end) {
+        if (!next_aux(p, end, f)) { err = "corrupt aux data"; return false; }
+        if (f.tag[0] == 'M' && f.tag[1] == 'M' && !has_mm) { mm = f; has_mm = true; }
+        if (f.tag[0] == 'M' && f.tag[1] == 'L' && !has_ml) { ml = f; has_ml = true; }
+    }
+    if (!has_ml || !has_mm) return true;  // nothing to parse (bam_mod_parser.cpp:250-256)
+    if (ml.type != 'B' || mm.type != 'Z') { err = "MM must be a Z tag and ML a B array"; return false; }
+    std::vector<uint8_t> probs(ml.count);
+    const int es = aux_elem_size(ml.subtype);
+    for (uint32_t i = 0; i < ml.count; ++i) {
+        int64_t v = 0;
+        const uint8_t* q = ml.payload + (size_t)i * es;
+        switch (ml.subtype) {
+        case 'C': v = q[0]; break;
+        case 'c': v = (int8_t)q[0]; break;
+        case 'S': v = rd16(q); break;
+        case 's': v = (int16_t)rd16(q); break;
+        case 'I': v = rd32(q); break;
+        case 'i': v = (int32_t)rd32(q); break;
+        default: err = "ML has a non-integer element type"; return false;
+        }
+        if (v < 0 || v > 255) { err = "Illegal scaled probability value, which must be in range [0, 255]"; return false; }
+        probs[i] = (uint8_t)v;
+    }
+    if (probs.empty()) return true;
+    const std::string mms(reinterpret_cast<const char*>(mm.payload));
+    if (mms.empty() || mms.back() != ';') { err = "The MM aux tag must end with ';'"; return false; }
+    const int L = r.l_qseq();
+    size_t pi = 0;
+    for (size_t i = 0; i < mms.size();) {
+        size_t j = mms.find(';', i);
+        const std::string s = mms.substr(i, j - i + 1);  // one edit series incl. ';'
+        i = j + 1;
+        if (s.size() < 4) { err = "Corrupted edit series " + s; return false; }
+        const char ub = s[0];
+        if (!strchr("CGTAUN", ub) || (s[1] != '+' && s[1] != '-')) { err = "Unrecognised base or strand in edit series " + s; return false; }
+        const uint8_t strand = s[1] == '+' ? 0 : 1;
+        std::string codes;
+        size_t si = 2;
+        if (isdigit((unsigned char)s[2])) {
+            long c = 0;
+            while (si < s.size() && isdigit((unsigned char)s[si])) c = c * 10 + (s[si++] - '0');
+            const char code = chebi_to_code(c);
+            if (!code) { err = "Unrecognised ChEBI code in edit series " + s; return false; }
+            codes += code;
+        } else {
+            for (; si < s.size() && s[si] != ',' && s[si] != ';'; ++si)
+                if (s[si] != '.' && s[si] != '?') codes += s[si];
+        }
+        std::vector<int> deltas;
+        while (si < s.size() && s[si] != ';') {
+            if (s[si] != ',') { err = "Illegal character in edit series " + s; return false; }
+            ++si;
+            if (si >= s.size() || !isdigit((unsigned char)s[si])) { err = "Illegal character in edit series " + s; return false; }
+            long d = 0;
+            while (si < s.size() && isdigit((unsigned char)s[si])) d = d * 10 + (s[si++] - '0');
+            deltas.push_back((int)d);
+        }
+        int qoff = 0;
+        for (int d : deltas) {  // bam_mod_parser.cpp:196-229
+            int cnt = 0;
+            while (cnt < d) {
+                if (qoff >= L) { err = "edit series runs past the read end: " + s; return false; }
+                if (fwd_strand_base(r, qoff) == ub) ++cnt;
+                ++qoff;
+            }
+            while (qoff < L && fwd_strand_base(r, qoff) != ub) ++qoff;
+            if (qoff >= L) { err = "edit series runs past the read end: " + s; return false; }
+            for (char code : codes) {
+                if (pi >= probs.size()) { err = "ML is shorter than the MM edit lists"; return false; }
+                mods.push_back(BaseMod{qoff, strand, ub, code, probs[pi++]});
+            }
+            ++qoff;
+        }
+    }
+    return true;
+}
+
+int mod_context(const BamRecord& r, int q) {
+    const int L = r.l_qseq();
+    auto b = [&](int k) { return (k >= 0 && k < L) ? fwd_strand_base(r, k) : 'N'; };
+    auto H = [](char c) { return c == 'A' || c == 'C' || c == 'T'; };
+    auto D = [](char c) { return c == 'A' || c == 'G' || c == 'T'; };
+    const char c0 = b(q);
+    if (c0 == 'C') {
+        if (b(q + 1) == 'G') return 0;
+        if (q + 2 < L && H(b(q + 1)) && b(q + 2) == 'G') return 1;
+        if (q + 2 < L && H(b(q + 1)) && H(b(q + 2))) return 2;
+        return -1;
+    }
+    if (c0 == 'G') return (q - 2 >= 0 && D(b(q - 1)) && D(b(q - 2))) ? 2 : -1;
+    return -1;
+}
+
+int resolve_threshold(const uint64_t* a, uint64_t* samples) {
+    uint64_t sum = 0, min_cnt = ~uint64_t(0);
+    int min_i = -1, st = 20, en = 256 - 20;
+    while (st < 256 && a[st] < 10) ++st;
+    while (en && a[en - 1] < 10) --en;
+    if (en - st >= 50)
+        for (int i = st; i < en; ++i) {
+            sum += a[i];
+            if (min_cnt > a[i]) { min_cnt = a[i]; min_i = i; }
+        }
+    if (samples) *samples = sum;
+    return (sum < 10000 || min_i == -1) ? 128 : min_i;
 }
 
 }  // namespace hmbam

@@ -101,4 +101,23 @@ char fwd_strand_base(const BamRecord& r, int k);
 // (the reference hbn_assert()s these).
 bool apply_calls(BamRecord& r, const hm_call_t* calls, size_t n, bool keep_kinetics, std::string& err);
 
+// ---- MM/ML parser (inverse of apply_calls) and the alignment-free part of `pileup` -------------------------
+// extract_bam_base_mods (src/corelib/bam_mod_parser.cpp:231-286): every (position, code) of the MM lists with its
+// ML probability, positions in forward-strand coordinates.
+struct BaseMod {
+    int32_t qoff;
+    uint8_t strand;   // 0 = '+', 1 = '-'
+    char unmod_base;  // C, G, ...
+    char code;        // 'm', 'h', ...
+    uint8_t prob;
+};
+bool parse_mods(const BamRecord& r, std::vector<BaseMod>& mods, std::string& err);
+
+// context of a 5mC call from the read sequence, as pileup does it for its histograms
+// (src/app/hifimeth/pileup.cpp:237-272): 0 CpG, 1 CHG, 2 CHH, -1 none
+int mod_context(const BamRecord& r, int qoff);
+
+// s_resolve_scaled_prob_threshold (pileup.cpp:355-436) for one 256-bin histogram; `samples` = the sum it reports
+int resolve_threshold(const uint64_t* bins, uint64_t* samples);
+
 }  // namespace hmbam

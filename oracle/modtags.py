@@ -23,3 +23,25 @@ def expected_tags(fwd_seq: bytes, qoff, strand, ml):
         parts.append(head + "".join(f",{int(d)}" for d in deltas) + ";")
         mls.append(ml[sel])
     return dict(MM="".join(parts), ML=np.concatenate(mls), MN=len(fwd_seq))
+
+
+def resolve_threshold(bins):
+    """s_resolve_scaled_prob_threshold for one context (src/app/hifimeth/pileup.cpp:355-436):
+    window [20, 236) trimmed on both sides while a bin holds < 10 samples; if the window is >= 50 bins wide the
+    threshold is the FIRST minimum bin of the window, else / with < 10000 samples in the window it is 128.
+    Returns (threshold, samples_in_window)."""
+    a = [int(x) for x in bins]
+    st, en = 20, 256 - 20
+    while st < 256 and a[st] < 10:
+        st += 1
+    while en and a[en - 1] < 10:
+        en -= 1
+    total, min_i, min_cnt = 0, -1, None
+    if en - st >= 50:
+        for i in range(st, en):
+            total += a[i]
+            if min_cnt is None or min_cnt > a[i]:
+                min_cnt, min_i = a[i], i
+    if total < 10000 or min_i == -1:
+        return 128, total
+    return min_i, total

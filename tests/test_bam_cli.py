@@ -142,3 +142,72 @@ def test_cli_call_end_to_end(tmp_path, oracle, oracle_models, ctx, mask):
         assert np.abs(tags["ML"][2].astype(int) - want["ML"].astype(int)).max() <= 1
         called += 1
     assert called >= 15
+
+
+def _modstats(path):
+    import json
+    return json.loads(subprocess.check_output([CLI, "modstats", path]))
+
+
+def test_mm_ml_parser_roundtrip_and_histograms(tmp_path, oracle, oracle_models):
+    """tagtest writes MM/ML from oracle calls; modstats parses them back (bam_mod_parser.cpp:231-286) and builds the
+    per-context probability histograms of pileup.cpp:237-272 -- they must equal the histograms of the calls."""
+    from oracle.modtags import resolve_threshold
+    reads = synth_reads(9, seed=6, median_len=2200, sigma=0.3, frac_wide=0.2, frac_short=0.1, frac_missing=0.1)
+    calls = _oracle_calls(oracle, oracle_models, reads)
+    src, dst, cb = str(tmp_path / "in.bam"), str(tmp_path / "out.bam"), str(tmp_path / "calls.bin")
+    bamutil.reads_to_bam(src, reads)
+    calls.tofile(cb)
+    subprocess.check_call([CLI, "tagtest", src, cb, dst])
+    st = _modstats(dst)
+    assert st["reads"] == len(reads) and st["calls"] == len(calls)
+    assert st["reads_with_mods"] == len(np.unique(calls["read_id"]))
+    for c, name in enumerate(("CpG", "CHG", "CHH")):
+        want = np.bincount(calls["scaled_prob"][calls["ctx"] == c], minlength=256)
+        assert st[name]["bins"] == want.tolist(), name
+        thr, n = resolve_threshold(want)
+        assert st[name]["threshold"] == thr and st[name]["samples_in_window"] == n
+    # the untouched input has no MM/ML at all
+    st0 = _modstats(src)
+    assert st0["calls"] == 0 and st0["reads_with_mods"] == 0 and st0["CpG"]["threshold"] == 128
+
+
+def test_threshold_rule_known_answers():
+    from oracle.modtags import resolve_threshold
+    flat = [1000] * 256
+    assert resolve_threshold(flat) == (20, 216000)            # first minimum of a flat window
+    valley = [5000 - abs(i - 140) * 0 for i in range(256)]
+    valley[140] = 11
+    assert resolve_threshold(valley)[0] == 140
+    few = [30] * 256                                            # 216 bins x 30 < 10000 samples -> fallback
+    assert resolve_threshold(few) == (128, 6480)
+    narrow = [0] * 256
+    for i in range(100, 140):
+        narrow[i] = 100000                                      # window narrower than 50 bins -> fallback
+    assert resolve_threshold(narrow) == (128, 0)
+    bimodal = [int(20000 * (np.exp(-((i - 30) / 18.0) ** 2) + np.exp(-((i - 225) / 15.0) ** 2))) + 12 for i in range(256)]
+    thr, n = resolve_threshold(bimodal)
+    assert thr == 20 + int(np.argmin(bimodal[20:236])) and 60 <= thr <= 200 and n > 10000   # first minimum of the valley
+
+
+def test_parser_accepts_foreign_mm_dialects_and_rejects_garbage(tmp_path):
+    """ChEBI code, '?' / '.' flags, multi-code lists (bam_mod_parser.cpp:36-77,150-160); malformed tags are errors."""
+    rd = synth_reads(1, seed=9, median_len=1200, sigma=0.05, frac_short=0, frac_missing=0, frac_wide=0)[0]
+    seq = rd.ascii()
+    cpos = [i for i, b in enumerate(seq) if b == ord("C")]
+
+    def bam_with(mm, ml):
+        path = str(tmp_path / "x.bam")
+        extra = lambda i, r: bamutil.aux_Z("MM", mm) + bamutil.aux_B("ML", np.array(ml, np.uint8))
+        bamutil.reads_to_bam(path, [rd], extra_aux=extra)
+        return path
+
+    st = _modstats(bam_with("C+27551,0,1;", [200, 17]))                 # ChEBI 27551 = 5mC
+    assert st["reads_with_mods"] == 1 and st["calls"] <= 2              # counted only where a context exists
+    st = _modstats(bam_with("C+m?,0;C+h.,0;", [9, 8]))                  # flags skipped; two lists share ML in order
+    assert st["reads_with_mods"] == 1
+    st = _modstats(bam_with("C+mh,2;", [11, 12]))                       # two codes per position consume two ML entries
+    assert st["reads_with_mods"] == 1
+    for mm, ml in (("C+m,0", [1]), ("C+m,99999;", [1]), ("C+m,0,0;", [1]), ("X+m,0;", [1]), ("C+m;0;", [1])):
+        p = bam_with(mm, ml)
+        assert subprocess.call([CLI, "modstats", p], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) != 0, mm
