@@ -195,7 +195,7 @@ def main():
             prep_b = bases * (4.5 + 1 + 4) + sites_step * 21 + bases            # raw in, packed out, site records, emit re-read
             feat["scan_kernels"] = {"prep_scan_emit_ms_per_step": (tm["prep_ms"] + tm["scan_ms"] + tm["emit_ms"]) / max(1, args.steps),
                                     "achieved_GBps": prep_b / ((tm["prep_ms"] + tm["scan_ms"] + tm["emit_ms"]) / max(1, args.steps) * 1e-3) / 1e9,
-                                    "note": "launch-latency sized at this batch (1.5 Mbases): three launches of 5-20 us"}
+                                    "note": f"three launches over {bases / 1e6:.1f} Mbases; launch-latency sized for small batches"}
     if rank == 0:
         front_ms = sum(tm["front_ms"])
         front_launches = sum(tm["front_launches"])

@@ -61,9 +61,14 @@ struct ConvH {
         return tap * IRS + (kk - tap * CIN);
     }
 
-    template <class Epi>
+    struct NoMark {
+        __device__ __forceinline__ void operator()(int) const {}
+    };
+
+    // `mark(0)` after the prologue loads are issued, `mark(1)` after the k-loop (diagnostic stamps only)
+    template <class Epi, class Mark = NoMark>
     static __device__ __forceinline__ void run(const half_t* __restrict__ in_hi, const half_t* __restrict__ in_lo,
-                                               const half_t* __restrict__ wfrag, Epi epi) {
+                                               const half_t* __restrict__ wfrag, Epi epi, Mark mark = Mark{}) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));  // keep this layer's address arithmetic out of the persistent site loop
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,6 +142,7 @@ struct ConvH {
                                                                            acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         };
+        mark(0);
         constexpr int UN = BR % 2 == 0 ? BR : 2 * BR;
         int kb = 0;
 #pragma nounroll
@@ -149,6 +155,7 @@ struct ConvH {
             ((R < KB % UN ? block(std::integral_constant<int, R % BR>{}, std::integral_constant<int, R % 2>{}, KB - KB % UN + R)
                           : (void)0), ...);
         }(std::make_integer_sequence<int, UN>{});
+        mark(1);
 
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
 
         // conv1: window (planes B) -> planes A
         ConvH<NW, 8, G::KT1, 128, G::L1, G::WRS, 2, 4, 2>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[0]),
-                                                             EpiPlanes<G::RS>{a_hi, a_lo, W.bias[0]});
+                                                             EpiPlanes<G::RS>{a_hi, a_lo, W.bias[0]}, [&](int k) __attribute__((always_inline)) { mk(2 + k); });
         mk(4);
         zero_rows_h<128>(a_hi, a_lo, 0, G::L1 + 1, G::RS);
         __syncthreads();
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
 
         // conv2: planes A -> planes B
         ConvH<NW, 128, 3, 128, G::L2, G::RS, 1, 8, 3, 1, 0, 0, !W16>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]),
-                                                           EpiPlanes<G::RS>{b_hi, b_lo, W.bias[1]});
+                                                           EpiPlanes<G::RS>{b_hi, b_lo, W.bias[1]}, [&](int k) __attribute__((always_inline)) { mk(6 + k); });
         mk(8);
         zero_rows_h<128>(b_hi, b_lo, 0, G::L2 + 1, G::RS);
         __syncthreads();
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
 
         // conv3: planes B -> planes A
         ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 4, 1, 0, 0, !W16>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
-                                                           EpiPlanes<G::RS>{a_hi, a_lo, W.bias[2]});
+                                                           EpiPlanes<G::RS>{a_hi, a_lo, W.bias[2]}, [&](int k) __attribute__((always_inline)) { mk(10 + k); });
         mk(12);
         zero_rows_h<128>(a_hi, a_lo, 0, G::L3 + 1, G::RS);
         __syncthreads();
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         // conv4: planes A -> act4[s] (fp32, hand-off to the tail kernel) on 6 waves (one 16-channel tile column
         // each, weights 5 k-blocks ahead); the other 2 build the next site's window in planes B meanwhile
         ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 6, 1, 0, 0, !W16>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]),
-                                                            EpiGlobalF<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]});
+                                                            EpiGlobalF<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]}, [&](int k) __attribute__((always_inline)) { mk(14 + k); });
         mk(16);
         const int sn = s + gridDim.x;
         if (sn < n_sites && (int)threadIdx.x >= 384) build_window(sn, threadIdx.x - 384, 128);
