@@ -288,6 +288,22 @@ def test_fp16_weights_mode_config5(mc, oracle, oracle_models):
     assert len(dp) > 5000 and dp.max() <= 5e-3 and (dp > 1e-3).mean() <= 2e-3 and dp.mean() <= 2e-4
 
 
+@pytest.mark.parametrize("spec,tag", [("cpg", "cpg"), ("cpg,chg,chh", "all")])
+def test_config1_committed_goldens(spec, tag):
+    """BASELINE.json configs[1]: CpG-only (and all-context) calls of a fixed read set against the COMMITTED CPU-path
+    outputs (tests/golden/config1_calls.npz, generated by tools/make_golden.py) -- no oracle needed at run time."""
+    from hifimeth_amd import MethylationCaller
+    z = np.load(os.path.join(GOLDEN, "config1_calls.npz"))
+    reads = synth_reads(int(z["n_reads"]), seed=20250220, gc=0.36, median_len=2400, sigma=0.35, frac_wide=0.2,
+                        frac_short=0.1, frac_missing=0.1)
+    with MethylationCaller(contexts=spec) as m:
+        calls = m.call(reads)
+    assert np.array_equal(calls["read_id"], z[f"{tag}_read"]) and np.array_equal(calls["qoff"], z[f"{tag}_qoff"])
+    assert np.array_equal(calls["strand"], z[f"{tag}_strand"]) and np.array_equal(calls["ctx"], z[f"{tag}_ctx"])
+    assert np.abs(calls["p"] - z[f"{tag}_p"]).max() <= DP_TOL
+    assert np.abs(calls["scaled_prob"].astype(int) - z[f"{tag}_ml"].astype(int)).max() <= 1
+
+
 def test_empty_and_skipped(mc):
     mc.clear()
     mc.upload()

@@ -129,3 +129,21 @@ def test_call_read_composition(oracle, oracle_models):
     assert (res["strand"][res["ctx"] < 2] == 0).all() and (res["strand"][res["ctx"] == 2] == 1).any()
     # skipped when shorter than -l (mod_main.cpp:189-192)
     assert len(oracle.call_read(oracle_models, 0b111, rd, min_len=10 ** 6)["qoff"]) == 0
+
+
+def test_config1_goldens_match_live_oracle(oracle, oracle_models):
+    """The committed CPU-path outputs of the configs[0] stand-in still equal what the oracle computes now."""
+    z = np.load(os.path.join(GOLDEN, "config1_calls.npz"))
+    reads = synth_reads(int(z["n_reads"]), seed=20250220, gc=0.36, median_len=2400, sigma=0.35, frac_wide=0.2,
+                        frac_short=0.1, frac_missing=0.1)
+    k = 0
+    for i, rd in enumerate(reads):
+        if not rd.has_kinetics() or rd.l_qseq < 1000:
+            continue
+        r = oracle.call_read(oracle_models, 1, rd)
+        order = np.lexsort((r["qoff"], r["strand"]))
+        n = len(order)
+        assert np.array_equal(z["cpg_qoff"][k:k + n], r["qoff"][order]) and (z["cpg_read"][k:k + n] == i).all()
+        assert np.abs(z["cpg_p"][k:k + n] - r["p"][order]).max() < 1e-6
+        k += n
+    assert k == len(z["cpg_qoff"]) > 300

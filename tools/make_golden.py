@@ -162,9 +162,36 @@ def make_cnn(wins):
     json.dump(report, open(os.path.join(GOLD, "cnn_report.json"), "w"), indent=1)
 
 
+def make_config_goldens():
+    """BASELINE.json configs[0]/[1] stand-in (the P.patens tutorial BAM is an external download): a small CpG-only
+    read set with the CPU path's outputs.  These vectors come from the ORACLE (which is pinned against the reference
+    by the fixtures above), not from the reference directly -- they freeze the CPU path so that the GPU tests can
+    be checked against committed numbers as well as against the live oracle."""
+    reads = synth_reads(10, seed=20250220, gc=0.36, median_len=2400, sigma=0.35, frac_wide=0.2, frac_short=0.1,
+                        frac_missing=0.1)
+    models = [O.Model(os.path.join(ROOT, "hifimeth_amd", "weights", n + ".hmw")) for n in ("CpG", "CHG", "CHH")]
+    out = dict(n_reads=len(reads))
+    for mask, tag in ((1, "cpg"), (7, "all")):
+        rid, qoff, strand, ctx, p, ml = [], [], [], [], [], []
+        for i, rd in enumerate(reads):
+            if not rd.has_kinetics() or rd.l_qseq < 1000:
+                continue
+            r = O.call_read(models, mask, rd)
+            order = np.lexsort((r["qoff"], r["strand"]))
+            rid += [i] * len(order)
+            qoff.append(r["qoff"][order]); strand.append(r["strand"][order]); ctx.append(r["ctx"][order])
+            p.append(r["p"][order]); ml.append(r["ml"][order])
+        out.update({f"{tag}_read": np.array(rid, np.int32), f"{tag}_qoff": np.concatenate(qoff),
+                    f"{tag}_strand": np.concatenate(strand), f"{tag}_ctx": np.concatenate(ctx),
+                    f"{tag}_p": np.concatenate(p), f"{tag}_ml": np.concatenate(ml)})
+        print(f"config golden ({tag}): {len(rid)} sites")
+    np.savez_compressed(os.path.join(GOLD, "config1_calls.npz"), **out)
+
+
 if __name__ == "__main__":
     if not O.ref_scan_available():
         raise SystemExit("build oracle/_ref first: make -C oracle")
     make_scan()
     w = make_windows()
     make_cnn(w)
+    make_config_goldens()
