@@ -187,17 +187,26 @@ int cmd_call(int argc, char** argv) {
         calls.resize((size_t)std::max<int64_t>(n, 0));
         const int64_t got = hm_drain(e, calls.data(), (int64_t)calls.size());
         if (got < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(e)); failed = true; return; }
+        // calls are grouped by read in submission order: find every read's range, then build the tags of all reads
+        // in parallel (the MM deltas walk every base of the read), then write in order
+        std::vector<size_t> first(sl.recs.size() + 1, 0);
         size_t ci = 0;
         for (size_t i = 0; i < sl.recs.size(); ++i) {
-            size_t cj = ci;
-            while (cj < (size_t)got && calls[cj].read_id == (int32_t)i) ++cj;
-            std::string e2;
-            if (!apply_calls(sl.recs[i], calls.data() + ci, cj - ci, o.keep_kinetics, e2)) {
-                fprintf(stderr, "[%s] read %zu: %s\n", kName, all_reads + i, e2.c_str());
+            first[i] = ci;
+            while (ci < (size_t)got && calls[ci].read_id == (int32_t)i) ++ci;
+        }
+        first[sl.recs.size()] = ci;
+        std::vector<std::string> errs(sl.recs.size());
+        parallel_run((int)sl.recs.size(), o.threads, [&](int i) {
+            apply_calls(sl.recs[(size_t)i], calls.data() + first[(size_t)i], first[(size_t)i + 1] - first[(size_t)i],
+                        o.keep_kinetics, errs[(size_t)i]);
+        });
+        for (size_t i = 0; i < sl.recs.size(); ++i) {
+            if (!errs[i].empty()) {
+                fprintf(stderr, "[%s] read %zu: %s\n", kName, all_reads + i, errs[i].c_str());
                 failed = true;
                 return;
             }
-            ci = cj;
             all_bases += (size_t)sl.recs[i].l_qseq();
             write_record(out, sl.recs[i]);
         }

@@ -49,6 +49,8 @@ struct RawBlock {
 
 }  // namespace
 
+void parallel_run(int n, int threads, const std::function<void(int)>& f) { parallel_for(n, threads, f); }
+
 // ------------------------------------------------------------------------------------------------
 // BGZF
 // ------------------------------------------------------------------------------------------------

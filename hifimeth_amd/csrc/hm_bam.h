@@ -7,12 +7,16 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
 #include "../../include/hifimeth_hip.h"
 
 namespace hmbam {
+
+// run f(0..n-1) on up to `threads` host threads (work-stealing counter); used for BGZF blocks and per-read tagging
+void parallel_run(int n, int threads, const std::function<void(int)>& f);
 
 class BgzfReader {
 public:

@@ -8,18 +8,18 @@ import numpy as np
 _EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
-def _bgzf_block(data: bytes) -> bytes:
-    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+def _bgzf_block(data: bytes, level: int = 6) -> bytes:
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
     comp = co.compress(data) + co.flush()
     bsize = 18 + len(comp) + 8 - 1
     return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + comp
             + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
 
 
-def write_bgzf(path, payload: bytes, block=0xff00):
+def write_bgzf(path, payload: bytes, block=0xff00, level: int = 6):
     with open(path, "wb") as f:
         for i in range(0, len(payload), block):
-            f.write(_bgzf_block(payload[i:i + block]))
+            f.write(_bgzf_block(payload[i:i + block], level))
         f.write(_EOF)
 
 
@@ -47,9 +47,9 @@ def record(name: str, flag: int, seq4: np.ndarray, l_seq: int, aux: bytes) -> by
     return struct.pack("<I", len(body)) + body
 
 
-def reads_to_bam(path, reads, header_text="@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n", extra_aux=None):
+def reads_to_bam(path, reads, header_text="@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n", extra_aux=None, level: int = 6):
     """reads: hifimeth_amd.synth.Read objects -> unaligned PacBio-style BAM with fi/fp/ri/rp (+ a few other tags)."""
-    out = b"BAM\1" + struct.pack("<I", len(header_text)) + header_text.encode() + struct.pack("<I", 0)
+    parts = [b"BAM\1" + struct.pack("<I", len(header_text)) + header_text.encode() + struct.pack("<I", 0)]
     for i, r in enumerate(reads):
         aux = aux_i("np", 10 + i) + aux_f("rq", 0.999) + aux_Z("RG", "rg0")
         for tag in ("fi", "fp", "ri", "rp"):
@@ -59,8 +59,8 @@ def reads_to_bam(path, reads, header_text="@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n",
         aux += aux_i("zm", i)
         if extra_aux:
             aux += extra_aux(i, r)
-        out += record(r.name, r.flag, r.seq4, r.l_qseq, aux)
-    write_bgzf(path, out)
+        parts.append(record(r.name, r.flag, r.seq4, r.l_qseq, aux))
+    write_bgzf(path, b"".join(parts), level=level)
 
 
 def parse_aux(aux: bytes):

@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 threads = sys.argv[2] if len(sys.argv) > 2 else "16"
 tmp = os.environ.get("TMPDIR", "/tmp")
 src, dst = os.path.join(tmp, "e2e_in.bam"), os.path.join(tmp, "e2e_out.bam")
-t = time.time(); reads = synth_reads(n, seed=20250220); bamutil.reads_to_bam(src, reads)
+t = time.time(); reads = synth_reads(n, seed=20250220); bamutil.reads_to_bam(src, reads, level=1)
 print(f"synthetic BAM: {n} reads, {sum(r.l_qseq for r in reads)/1e6:.1f} Mbases, {os.path.getsize(src)/1e6:.1f} MB, built in {time.time()-t:.1f} s", flush=True)
 cli = os.path.join(ROOT, "hifimeth_amd", "bin", "hifimeth-hip")
 for b in ("250", "1000"):
