@@ -381,6 +381,9 @@ int hm_submit_read(hm_engine_t* e, int32_t read_id, int32_t l_qseq, int32_t flag
     if (l_qseq < e->min_read_size) return 0;        // mod_main.cpp:189-192
     if (!fi || !fp || !ri || !rp) return 0;          // BamKinetics::init false (bam_info.cpp:572-603)
     if (!seq4) return fail(e, HM_EINVAL, "hm_submit_read: seq4 is NULL");
+    // site ranks and per-base offsets inside one batch are 32-bit on the device: keep a batch under 2^31 bases
+    if (e->total_bases + (int64_t)l_qseq + 4 >= (int64_t(1) << 31))
+        return fail(e, HM_ENOMEM, "hm_submit_read: batch would exceed 2^31 bases; hm_flush / hm_drain first");
     const int w[4] = {fi_w, fp_w, ri_w, rp_w};
     for (int k = 0; k < 4; ++k)
         if (w[k] != 1 && w[k] != 2) return fail(e, HM_EINVAL, "kinetics element width must be 1 (B:C) or 2 (B:S)");

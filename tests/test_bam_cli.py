@@ -126,7 +126,8 @@ def test_cli_call_end_to_end(tmp_path, oracle, oracle_models, ctx, mask):
     reads = synth_reads(25, seed=44, median_len=2500, sigma=0.4, frac_wide=0.1, frac_short=0.1, frac_missing=0.1)
     src, dst = str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
     bamutil.reads_to_bam(src, reads)
-    subprocess.check_call([CLI, "call", "-c", ctx, "-b", "7", "-t", "4", src, dst])   # small -b: several batches in flight
+    # small -b: several batches in flight; "-d 0,0" drives the multi-device round-robin (4 engines) on the one GPU
+    subprocess.check_call([CLI, "call", "-c", ctx, "-b", "7", "-t", "4", "-d", "0,0" if mask == 7 else "0", src, dst])
     _, recs = bamutil.read_bam(dst)
     assert [r["name"] for r in recs] == [r.name for r in reads]           # input order preserved
     called = 0
