@@ -304,6 +304,18 @@ def test_config1_committed_goldens(spec, tag):
     assert np.abs(calls["scaled_prob"].astype(int) - z[f"{tag}_ml"].astype(int)).max() <= 1
 
 
+def test_very_long_read_and_many_small_reads(mc, oracle, oracle_models):
+    """A 70 kb read (69 scan chunks, l_qseq > 65535) next to a crowd of minimum-length reads."""
+    rng = np.random.default_rng(23)
+    L = 70001
+    long_read = read_from_ascii("".join("ACGT"[i] for i in rng.choice(4, L, p=[0.32, 0.18, 0.18, 0.32])).encode(), *_kin(L, rng))
+    small = [read_from_ascii("".join("ACGT"[i] for i in rng.choice(4, 1000)).encode(), *_kin(1000, rng)) for _ in range(40)]
+    reads = small[:20] + [long_read] + small[20:]
+    calls = mc.call(reads)
+    n, _, worst = _check_calls(calls, reads, oracle, oracle_models, 7)
+    assert n > 30000 and (calls["read_id"] == 20).sum() > 15000
+
+
 def test_empty_and_skipped(mc):
     mc.clear()
     mc.upload()
