@@ -70,6 +70,21 @@ def lib():
         "hm_get_stamps": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
         "hm_get_timing": (C.c_int, [vp, C.POINTER(hm_timing_t)]),
         "hm_reset_timing": (C.c_int, [vp]),
+        # pileup
+        "hm_pileup_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "hm_pileup_destroy": (None, [vp]),
+        "hm_pileup_last_error": (cp, [vp]),
+        "hm_pileup_set_option": (C.c_int, [vp, cp, C.c_double]),
+        "hm_pileup_set_reference": (C.c_int, [vp, i32, vp, vp]),
+        "hm_pileup_use_planes": (C.c_int, [vp, vp, vp, vp]),
+        "hm_pileup_planes": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]),
+        "hm_pileup_submit_read": (C.c_int, [vp, C.c_uint32, i32, i32, i64, i32, i32, vp, i32, vp, i64, vp]),
+        "hm_pileup_run": (C.c_int, [vp]),
+        "hm_pileup_num_records": (i64, [vp]),
+        "hm_pileup_histograms": (C.c_int, [vp, vp]),
+        "hm_pileup_fetch_records": (i64, [vp, vp, vp, vp, vp, i64]),
+        "hm_pileup_count": (C.c_int, [vp, vp]),
+        "hm_pileup_fetch_loci": (i64, [vp, vp, vp, vp, i64, i64, i64, vp, i64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -6,6 +6,7 @@
 // Two extra sub-commands need no GPU and exist for the CPU test-suite:
 //     hifimeth-hip bamcopy IN.bam OUT.bam             (BGZF/BAM round trip)
 //     hifimeth-hip tagtest IN.bam CALLS.bin OUT.bam   (apply hm_call_t records, read_id = record index)
+//     hifimeth-hip pileup [OPTIONS] REF.fa MOD.bam PREFIX   (hifimeth_pileup.cpp)
 //     hifimeth-hip modstats IN.bam                    (MM/ML parser + per-context histograms + adaptive thresholds)
 #include <unistd.h>
 
@@ -351,6 +352,9 @@ int cmd_modstats(int argc, char** argv) {
 
 }  // namespace
 
+int cmd_pileup(int argc, char** argv);   // hifimeth_pileup.cpp
+int cmd_fastats(int argc, char** argv);  // hifimeth_pileup.cpp
+
 int main(int argc, char** argv) {
     if (argc < 2) { usage(); return EXIT_FAILURE; }
     const std::string cmd = argv[1];
@@ -358,6 +362,8 @@ int main(int argc, char** argv) {
     if (cmd == "bamcopy") return cmd_bamcopy(argc, argv);
     if (cmd == "tagtest") return cmd_tagtest(argc, argv);
     if (cmd == "modstats") return cmd_modstats(argc, argv);
+    if (cmd == "pileup") return cmd_pileup(argc, argv);
+    if (cmd == "fastats") return cmd_fastats(argc, argv);
     usage();
     return EXIT_FAILURE;
 }

@@ -1,0 +1,235 @@
+// hifimeth_pileup.cpp -- `hifimeth-hip pileup [OPTIONS] reference mod-bam output-prefix`
+// Same command line, stderr messages and output files as `hifimeth pileup` (src/app/hifimeth/pileup.cpp:22-112,
+// 461-606): <prefix>.CpG.cov.bed, <prefix>.CHG.cov.bed, <prefix>.CHH.cov.bed with rows
+//   chrom <tab> soff <tab> soff+1 <tab> 100*pcov/(pcov+ncov) <tab> pcov <tab> ncov
+// The host parses the BAM and the MM/ML lists (parallel over the reads of a batch); alignment projection,
+// histograms and per-locus counting run on the GPU through the hm_pileup_* C ABI.  No temporary file is written:
+// the projected calls stay in HBM until the thresholds are known.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hifimeth_hip.h"
+#include "hm_bam.h"
+
+using namespace hmbam;
+
+namespace {
+
+struct PileupOptions {
+    int min_mapq = 0;     // kMinMapQ
+    double min_pi = 0.0;  // kMinPi
+    int threads = 8;      // kNumThreads
+    int device = 0;
+    int read_batch = 4096;
+    std::string ref, bam, prefix;
+};
+
+void pileup_usage(const char* exe) {
+    fprintf(stderr,
+            "USAGE:\n  %s pileup [OPTIONS] reference mod-bam output-prefix\n\n"
+            "DESCRIPTION:\n  Compute aggregate cytosine methylation states on the genomic reference\n\n"
+            "OPTIONAL ARGUMENTS:\n"
+            "  -q <mapQ>\n    Minimum mapping quality score\n    Default: 0\n"
+            "  -f <Alignment identity>\n    Default: 0\n"
+            "  -t <CPU threads>\n    Number of CPU threads\n    Default: 8\n"
+            "  -d <int>\n    GPU ordinal\n    Default: 0\n"
+            "  -b <int>\n    BAM records per GPU batch\n    Default: 4096\n",
+            exe);
+}
+
+// s_bam_is_mapped_and_sorted (pileup.cpp:438-459)
+bool mapped_and_sorted(const BamHeader& h) {
+    bool sorted = false;
+    size_t p = 0;
+    while (p < h.text.size()) {
+        size_t e = h.text.find('\n', p);
+        if (e == std::string::npos) e = h.text.size();
+        const std::string line = h.text.substr(p, e - p);
+        if (line.rfind("@HD", 0) == 0) {
+            size_t q = 0;
+            while ((q = line.find('\t', q)) != std::string::npos) {
+                ++q;
+                if (line.compare(q, 3, "SO:") == 0) {
+                    size_t t = line.find('\t', q);
+                    sorted = line.substr(q + 3, t == std::string::npos ? t : t - q - 3) == "coordinate";
+                }
+            }
+        }
+        p = e + 1;
+    }
+    const bool mapped = !h.refs.empty();
+    if (!mapped || !sorted) {
+        fprintf(stderr, "ERROR: Methylation frequency could not be computed due to the following errors:\n");
+        if (!mapped) fprintf(stderr, "BAM is not mapped\n");
+        if (!sorted) fprintf(stderr, "BAM is not sorted\n");
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+// fastats REF.fa : names, lengths and a checksum of the loaded reference as one JSON object (loader tests; no GPU)
+int cmd_fastats(int argc, char** argv) {
+    if (argc != 3) return EXIT_FAILURE;
+    Fasta fa;
+    std::string err;
+    if (!load_fasta(argv[2], fa, err)) { fprintf(stderr, "ERROR: %s\n", err.c_str()); return EXIT_FAILURE; }
+    printf("{\"seqs\": [");
+    size_t off = 0;
+    for (size_t i = 0; i < fa.names.size(); ++i) {
+        uint64_t h = 1469598103934665603ull;  // FNV-1a over the upper-cased bases
+        for (int64_t k = 0; k < fa.length[i]; ++k) h = (h ^ (uint8_t)fa.bases[off + (size_t)k]) * 1099511628211ull;
+        off += (size_t)fa.length[i];
+        printf("%s{\"name\": \"%s\", \"length\": %lld, \"fnv1a\": \"%016llx\"}", i ? ", " : "", fa.names[i].c_str(),
+               (long long)fa.length[i], (unsigned long long)h);
+    }
+    printf("]}\n");
+    return 0;
+}
+
+int cmd_pileup(int argc, char** argv) {
+    PileupOptions o;
+    int i = 2;
+    for (; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "-h") { pileup_usage(argv[0]); return 0; }
+        if (a.size() < 2 || a[0] != '-') break;
+        if (i + 1 >= argc) { pileup_usage(argv[0]); return EXIT_FAILURE; }
+        if (a == "-q") o.min_mapq = atoi(argv[++i]);
+        else if (a == "-f") o.min_pi = atof(argv[++i]);
+        else if (a == "-t") o.threads = std::max(1, atoi(argv[++i]));
+        else if (a == "-d") o.device = atoi(argv[++i]);
+        else if (a == "-b") o.read_batch = std::max(1, atoi(argv[++i]));
+        else { fprintf(stderr, "ERROR: unrecognised option %s", a.c_str()); pileup_usage(argv[0]); return EXIT_FAILURE; }
+    }
+    if (argc - i != 3) { pileup_usage(argv[0]); return EXIT_FAILURE; }
+    o.ref = argv[i];
+    o.bam = argv[i + 1];
+    o.prefix = argv[i + 2];
+    fprintf(stderr, "\n\n====================> Parameters:\nmin-mapQ: %d\nmin-identity: %g\nCPU threads: %d\n"
+                    "Genomic reference: %s\nmod-bam: %s\noutput prefix: %s\n\n\n",
+            o.min_mapq, o.min_pi, o.threads, o.ref.c_str(), o.bam.c_str(), o.prefix.c_str());
+
+    BgzfReader in(o.bam, o.threads);
+    BamHeader hdr;
+    std::string err;
+    if (!in.ok() || !read_header(in, hdr, err)) { fprintf(stderr, "ERROR: %s%s\n", in.error().c_str(), err.c_str()); return EXIT_FAILURE; }
+    if (!mapped_and_sorted(hdr)) return 1;
+
+    Fasta fa;
+    if (!load_fasta(o.ref, fa, err)) { fprintf(stderr, "ERROR: %s\n", err.c_str()); return EXIT_FAILURE; }
+    fprintf(stderr, "Load %zu sequences (%zu bases) from %s\n", fa.names.size(), fa.bases.size(), o.ref.c_str());
+    std::vector<int> tid2sid(hdr.refs.size(), -2);  // resolved at first use, as HbnDatabase::seq_name2id
+
+    hm_pileup_t* pe = nullptr;
+    if (hm_pileup_create(&pe, o.device) != HM_OK) { fprintf(stderr, "ERROR: %s\n", hm_pileup_last_error(nullptr)); return EXIT_FAILURE; }
+    auto die = [&](const std::string& what) {
+        fprintf(stderr, "ERROR: %s: %s\n", what.c_str(), hm_pileup_last_error(pe));
+        hm_pileup_destroy(pe);
+        return EXIT_FAILURE;
+    };
+    hm_pileup_set_option(pe, "min_mapq", o.min_mapq);
+    hm_pileup_set_option(pe, "min_pi", o.min_pi);
+    if (fa.names.empty()) { fprintf(stderr, "ERROR: no sequence in %s\n", o.ref.c_str()); hm_pileup_destroy(pe); return EXIT_FAILURE; }
+    if (hm_pileup_set_reference(pe, (int32_t)fa.names.size(), fa.length.data(), fa.bases.data()) != HM_OK) return die("reference");
+
+    std::vector<BamRecord> batch((size_t)o.read_batch);
+    std::vector<std::vector<BaseMod>> mods((size_t)o.read_batch);
+    std::vector<std::string> perr((size_t)o.read_batch);
+    uint64_t n_records = 0;
+    bool more = true;
+    while (more) {
+        int n = 0;
+        while (n < o.read_batch && (more = read_record(in, batch[(size_t)n], err))) ++n;
+        if (!err.empty()) { fprintf(stderr, "ERROR: Could not read BAM record: %s\n", err.c_str()); hm_pileup_destroy(pe); return EXIT_FAILURE; }
+        parallel_run(n, o.threads, [&](int k) {
+            mods[(size_t)k].clear();
+            perr[(size_t)k].clear();
+            if (!parse_mods(batch[(size_t)k], mods[(size_t)k], perr[(size_t)k])) mods[(size_t)k].clear();
+        });
+        for (int k = 0; k < n; ++k) {
+            const BamRecord& r = batch[(size_t)k];
+            const uint64_t order = n_records++;
+            if (!perr[(size_t)k].empty()) {
+                fprintf(stderr, "ERROR at parsing read %s\n%s\n", reinterpret_cast<const char*>(r.data.data() + 32), perr[(size_t)k].c_str());
+                hm_pileup_destroy(pe);
+                return EXIT_FAILURE;
+            }
+            if (mods[(size_t)k].empty() || (r.flag() & 4)) continue;
+            const int tid = r.ref_id();
+            if (tid < 0 || tid >= (int)hdr.refs.size()) { fprintf(stderr, "ERROR: mapped record without a reference id\n"); hm_pileup_destroy(pe); return EXIT_FAILURE; }
+            if (tid2sid[(size_t)tid] == -2) tid2sid[(size_t)tid] = fa.find(hdr.refs[(size_t)tid].first);
+            if (tid2sid[(size_t)tid] < 0) {
+                fprintf(stderr, "ERROR: Sequence name %s does not exist\n", hdr.refs[(size_t)tid].first.c_str());
+                hm_pileup_destroy(pe);
+                return EXIT_FAILURE;
+            }
+            std::vector<uint32_t> cig((size_t)r.n_cigar());
+            if (!cig.empty()) memcpy(cig.data(), r.cigar_bytes(), 4 * cig.size());
+            const int rc = hm_pileup_submit_read(pe, (uint32_t)order, r.flag(), tid2sid[(size_t)tid], r.pos(), r.mapq(), r.l_qseq(),
+                                                 r.seq4(), r.n_cigar(), cig.data(), (int64_t)mods[(size_t)k].size(),
+                                                 mods[(size_t)k].data());
+            if (rc < 0) return die(std::string("read ") + reinterpret_cast<const char*>(r.data.data() + 32));
+        }
+        if (hm_pileup_run(pe) != HM_OK) return die("projection");
+    }
+
+    static uint64_t bins[768];
+    if (hm_pileup_histograms(pe, bins) != HM_OK) return die("histograms");
+    uint8_t thr[3];
+    static const char* cn[3] = {"CpG", "CHG", "CHH"};
+    for (int c = 0; c < 3; ++c) {  // s_resolve_scaled_prob_threshold (pileup.cpp:355-436)
+        uint64_t samples = 0;
+        const int t = resolve_threshold(bins + 256 * c, &samples);
+        fprintf(stderr, "%s samples: %llu\n", cn[c], (unsigned long long)samples);
+        const uint64_t* a = bins + 256 * c;  // the fallback branch: window narrower than 50 bins or < 10000 samples
+        int st = 20, en = 256 - 20;
+        while (st < 256 && a[st] < 10) ++st;
+        while (en && a[en - 1] < 10) --en;
+        const bool fallback = samples < 10000 || en - st < 50;
+        if (fallback) fprintf(stderr, "Not enough samples for inferring scaled probability threshold, set it to 128\n");
+        else fprintf(stderr, "%s scaled probability threshold: %d\n", cn[c], t);
+        thr[c] = (uint8_t)t;
+    }
+    if (hm_pileup_count(pe, thr) != HM_OK) return die("count");
+
+    FILE* out[3];
+    for (int c = 0; c < 3; ++c) {
+        const std::string path = o.prefix + "." + cn[c] + ".cov.bed";
+        out[c] = fopen(path.c_str(), "w");
+        if (!out[c]) { fprintf(stderr, "ERROR: cannot open %s for writing\n", path.c_str()); hm_pileup_destroy(pe); return EXIT_FAILURE; }
+    }
+    std::vector<hm_locus_t> loci;
+    std::string text[3];
+    int64_t off = 0;
+    for (size_t s = 0; s < fa.names.size(); ++s) {
+        const int64_t lo = off, hi = off + fa.length[s];
+        off = hi;
+        int64_t n = hm_pileup_fetch_loci(pe, nullptr, nullptr, nullptr, 0, lo, hi, nullptr, 0);
+        if (n < 0) return die("loci");
+        if (n == 0) continue;
+        loci.resize((size_t)n);
+        n = hm_pileup_fetch_loci(pe, nullptr, nullptr, nullptr, 0, lo, hi, loci.data(), n);
+        if (n < 0) return die("loci");
+        for (auto& t : text) t.clear();
+        char row[256];
+        for (const hm_locus_t& l : loci) {  // pileup.cpp:562-586
+            const int64_t k = l.gpos - lo;
+            const double freq = 100.0 * l.pcov / (l.pcov + l.ncov);
+            const int len = snprintf(row, sizeof row, "\t%lld\t%lld\t%g\t%d\t%d\n", (long long)k, (long long)k + 1, freq, l.pcov, l.ncov);
+            std::string& t = text[l.motif < 3 ? l.motif : 2];
+            t += fa.names[s];
+            t.append(row, (size_t)len);
+        }
+        for (int c = 0; c < 3; ++c)
+            if (!text[c].empty()) fwrite(text[c].data(), 1, text[c].size(), out[c]);
+    }
+    for (FILE* f : out) fclose(f);
+    hm_pileup_destroy(pe);
+    return 0;
+}

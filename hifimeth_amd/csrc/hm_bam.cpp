@@ -8,6 +8,7 @@
 #include <cctype>
 #include <cstring>
 #include <thread>
+#include <unordered_set>
 
 namespace hmbam {
 
@@ -227,6 +228,8 @@ bool BgzfWriter::close() {
 int32_t BamRecord::l_qseq() const { return (int32_t)rd32(data.data() + 16); }
 uint16_t BamRecord::flag() const { return rd16(data.data() + 14); }
 int BamRecord::n_cigar() const { return rd16(data.data() + 12); }
+int32_t BamRecord::ref_id() const { return (int32_t)rd32(data.data()); }
+int32_t BamRecord::pos() const { return (int32_t)rd32(data.data() + 4); }
 const uint8_t* BamRecord::seq4() const { return data.data() + 32 + l_read_name() + 4 * (size_t)n_cigar(); }
 size_t BamRecord::aux_offset() const {
     const size_t L = (size_t)l_qseq();
@@ -591,6 +594,63 @@ int resolve_threshold(const uint64_t* a, uint64_t* samples) {
         }
     if (samples) *samples = sum;
     return (sum < 10000 || min_i == -1) ? 128 : min_i;
+}
+
+int Fasta::find(const std::string& name) const {
+    for (size_t i = 0; i < names.size(); ++i)
+        if (names[i] == name) return (int)i;
+    return -1;
+}
+
+bool load_fasta(const std::string& path, Fasta& fa, std::string& err) {
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) { err = "cannot open " + path; return false; }
+    gzbuffer(f, 1 << 20);
+    fa = Fasta();
+    std::vector<char> buf(1 << 22);
+    std::string line;
+    bool in_seq = false;  // a header has been seen
+    auto flush_line = [&]() {
+        size_t a = 0, b = line.size();
+        while (a < b && isspace((unsigned char)line[a])) ++a;
+        while (b > a && isspace((unsigned char)line[b - 1])) --b;
+        if (a == b) return;
+        const char c = line[a];
+        if (c == '!' || c == '#' || c == ';') return;
+        bool is_id = false;
+        for (size_t i = a; i < b && i - a <= 32; ++i)
+            if (isdigit((unsigned char)line[i]) || line[i] == '|') { is_id = true; break; }
+        if (is_id || c == '>') {
+            size_t s = a + (c == '>' ? 1 : 0), e = s;
+            while (e < b && !isspace((unsigned char)line[e])) ++e;
+            if (e == s) { in_seq = false; return; }  // the reference drops sequences with an empty name
+            fa.names.push_back(line.substr(s, e - s));
+            fa.length.push_back(0);
+            in_seq = true;
+        } else if (in_seq) {
+            for (size_t i = a; i < b; ++i) fa.bases.push_back((char)toupper((unsigned char)line[i]));
+            fa.length.back() += (int64_t)(b - a);
+        }
+    };
+    int n;
+    while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) {
+        int s = 0;
+        for (int i = 0; i < n; ++i)
+            if (buf[i] == '\n') {
+                line.append(buf.data() + s, i - s);
+                flush_line();
+                line.clear();
+                s = i + 1;
+            }
+        line.append(buf.data() + s, n - s);
+    }
+    if (n < 0) { err = "read error in " + path; gzclose(f); return false; }
+    flush_line();
+    gzclose(f);
+    std::unordered_set<std::string> seen;
+    for (const std::string& nm : fa.names)
+        if (!seen.insert(nm).second) { err = "Duplicate sequence name " + nm; return false; }
+    return true;
 }
 
 }  // namespace hmbam

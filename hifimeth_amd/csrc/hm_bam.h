@@ -66,6 +66,10 @@ struct BamRecord {
     uint16_t flag() const;
     int l_read_name() const { return data[8]; }
     int n_cigar() const;
+    int32_t ref_id() const;
+    int32_t pos() const;
+    int mapq() const { return data[9]; }
+    const uint8_t* cigar_bytes() const { return data.data() + 32 + l_read_name(); }  // n_cigar little-endian u32
     const uint8_t* seq4() const;
     size_t aux_offset() const;
 };
@@ -108,13 +112,7 @@ bool apply_calls(BamRecord& r, const hm_call_t* calls, size_t n, bool keep_kinet
 // ---- MM/ML parser (inverse of apply_calls) and the alignment-free part of `pileup` -------------------------
 // extract_bam_base_mods (src/corelib/bam_mod_parser.cpp:231-286): every (position, code) of the MM lists with its
 // ML probability, positions in forward-strand coordinates.
-struct BaseMod {
-    int32_t qoff;
-    uint8_t strand;   // 0 = '+', 1 = '-'
-    char unmod_base;  // C, G, ...
-    char code;        // 'm', 'h', ...
-    uint8_t prob;
-};
+using BaseMod = hm_mod_t;  // {qoff, strand (0 '+', 1 '-'), unmod_base, code, prob}
 bool parse_mods(const BamRecord& r, std::vector<BaseMod>& mods, std::string& err);
 
 // context of a 5mC call from the read sequence, as pileup does it for its histograms
@@ -123,5 +121,16 @@ int mod_context(const BamRecord& r, int qoff);
 
 // s_resolve_scaled_prob_threshold (pileup.cpp:355-436) for one 256-bin histogram; `samples` = the sum it reports
 int resolve_threshold(const uint64_t* bins, uint64_t* samples);
+
+// ---- reference genome (HbnDatabase, src/corelib/hbn_seqdb.cpp:37-95) -------------------------------------------
+// plain or gzip FASTA; bases upper-cased; a line is a header when it starts with '>' or holds a digit or '|' among
+// its first 33 characters (s_IsSeqID); lines starting with ! # ; are skipped; the name ends at the first blank.
+struct Fasta {
+    std::vector<std::string> names;
+    std::vector<int64_t> length;
+    std::string bases;  // all sequences back to back
+    int find(const std::string& name) const;  // -1 if absent
+};
+bool load_fasta(const std::string& path, Fasta& fa, std::string& err);
 
 }  // namespace hmbam

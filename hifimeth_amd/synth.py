@@ -99,3 +99,157 @@ def expected_sites_per_base(gc: float) -> float:
     """CpG + CHG (fwd only) + CHH (both strands) density for i.i.d. bases."""
     c = gc / 2
     return c * c + c * c * (1 - c) + 2 * c * (1 - c) ** 2
+
+
+# ---- aligned, modification-tagged reads for `pileup` ------------------------------------------------------------
+@dataclass
+class AlignedRead:
+    """One mapped mod-BAM record (what `hifimeth call` + pbmm2 hand to `hifimeth pileup`)."""
+    name: str
+    flag: int            # 0 / 16, optionally | 0x100 / 0x800; 4 = unmapped
+    tid: int
+    pos: int
+    mapq: int
+    cigar: list          # [(op_char, len)]
+    seq: str             # SEQ as stored (reference orientation)
+    mm: Optional[str]
+    ml: Optional[np.ndarray]
+
+    @property
+    def l_qseq(self) -> int:
+        return len(self.seq)
+
+    @property
+    def seq4(self) -> np.ndarray:
+        lut = np.full(256, 4, np.uint8)
+        lut[[65, 67, 71, 84]] = [0, 1, 2, 3]
+        return pack_codes(lut[np.frombuffer(self.seq.encode(), np.uint8)])
+
+    def cigar_string(self) -> str:
+        return "".join(f"{n}{op}" for op, n in self.cigar) or "*"
+
+    def cigar_u32(self) -> np.ndarray:
+        return np.array([(n << 4) | "MIDNSHP=XB".index(op) for op, n in self.cigar], np.uint32)
+
+
+_RC = bytes.maketrans(b"ACGTN", b"TGCAN")
+
+
+def revcomp(s: str) -> str:
+    return s.encode().translate(_RC)[::-1].decode()
+
+
+def synth_genome(n_chr: int = 2, length: int = 20000, gc: float = 0.4, seed: int = 3, n_frac: float = 0.001):
+    """-> [(name, SEQ)]; a few N runs so that alignments cross non-ACGT reference bases."""
+    rng = np.random.default_rng(seed)
+    p = [(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2]
+    out = []
+    for c in range(n_chr):
+        L = int(length * (1 + 0.3 * c))
+        s = _ASCII[rng.choice(4, L, p=p)].copy()
+        for _ in range(int(L * n_frac / 5) + 1):
+            a = int(rng.integers(0, L - 5))
+            s[a:a + 5] = ord("N")
+        out.append((f"chr{c + 1}", s.tobytes().decode()))
+    return out
+
+
+def _call_like_mods(fwd: str, rng, level, frac_called: float = 0.97):
+    """MM/ML as `hifimeth call` writes them (build_mod_bam.cpp:125-248): C+m on CpG / CHG / CHH cytosines of the
+    forward strand, G-m on the G of [AGT][AGT]G; `level(k)` = methylation level of forward offset k."""
+    s = np.frombuffer(fwd.encode(), np.uint8)
+    L = len(s)
+    C, G = ord("C"), ord("G")
+    n1 = np.concatenate([s[1:], [0]])
+    n2 = np.concatenate([s[2:], [0, 0]])
+    p1 = np.concatenate([[0], s[:-1]])
+    p2 = np.concatenate([[0, 0], s[:-2]])
+    isH = lambda x: (x == 65) | (x == 67) | (x == 84)  # noqa: E731
+    isD = lambda x: (x == 65) | (x == 71) | (x == 84)  # noqa: E731
+    fwd_c = (s == C) & ((n1 == G) | (isH(n1) & ((n2 == G) | isH(n2))))
+    rev_g = (s == G) & isD(p1) & isD(p2) & (np.arange(L) >= 2)
+    parts, mls = [], []
+    for mask, base, head in ((fwd_c, C, "C+m"), (rev_g, G, "G-m")):
+        q = np.nonzero(mask & (rng.random(L) < frac_called))[0]
+        if len(q) == 0:
+            continue
+        cnt = np.concatenate([[0], np.cumsum(s == base)])
+        last = np.concatenate([[0], q[:-1] + 1])
+        parts.append(head + "".join(f",{int(d)}" for d in cnt[q] - cnt[last]) + ";")
+        meth = rng.random(len(q)) < np.array([level(int(k)) for k in q])
+        pr = np.where(meth, 255 - rng.gamma(1.2, 18, len(q)), rng.gamma(1.2, 18, len(q)))
+        mls.append(np.clip(np.rint(pr), 0, 255).astype(np.uint8))
+    if not parts:
+        return None, None
+    return "".join(parts), np.concatenate(mls)
+
+
+def synth_alignments(genome, n_reads: int = 40, seed: int = 5, median_len: int = 3000, err: float = 0.01,
+                     eqx: bool = True, frac_unmapped: float = 0.05, frac_supp: float = 0.05,
+                     frac_no_mods: float = 0.05) -> List[AlignedRead]:
+    """Reads sampled from `genome` with substitutions / insertions / deletions at rate `err`, soft clips on some
+    reads, both strands, coordinate-sorted.  `eqx`: CIGAR with =/X (pbmm2 default) instead of M.
+    Per-locus methylation level is a deterministic function of the position, so the pileup has structure."""
+    rng = np.random.default_rng(seed)
+    reads = []
+    for i in range(n_reads):
+        tid = int(rng.integers(0, len(genome)))
+        chrom = genome[tid][1]
+        L = int(np.clip(rng.lognormal(np.log(median_len), 0.3), 300, len(chrom) - 10))
+        pos = int(rng.integers(0, len(chrom) - L))
+        ops, q = [], []
+        for k in range(pos, pos + L):
+            r = rng.random()
+            b = chrom[k]
+            if r < err / 3:
+                ops.append("D")
+            elif r < 2 * err / 3:
+                q.append("ACGT"[int(rng.integers(0, 4))]); ops.append("I")
+                q.append(b); ops.append("=" if eqx else "M")
+            elif r < err:
+                nb = "ACGT"[int(rng.integers(0, 4))]
+                q.append(nb); ops.append(("=" if nb == b else "X") if eqx else "M")
+            else:
+                q.append(b if b != "N" else "ACGT"[int(rng.integers(0, 4))])
+                ops.append(("=" if b != "N" else "X") if eqx else "M")
+        while ops and ops[0] in "DI":      # alignments start and end on an aligned pair
+            if ops[0] == "I":
+                q.pop(0)
+            else:
+                pos += 1
+            ops.pop(0)
+        while ops and ops[-1] in "DI":
+            if ops[-1] == "I":
+                q.pop()
+            ops.pop()
+        cig = []
+        for o in ops:
+            if cig and cig[-1][0] == o:
+                cig[-1][1] += 1
+            else:
+                cig.append([o, 1])
+        lead = int(rng.integers(0, 30)) if rng.random() < 0.3 else 0
+        trail = int(rng.integers(0, 30)) if rng.random() < 0.3 else 0
+        clip = lambda n: "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))  # noqa: E731
+        seq = clip(lead) + "".join(q) + clip(trail)
+        cigar = ([("S", lead)] if lead else []) + [(o, n) for o, n in cig] + ([("S", trail)] if trail else [])
+        rev = bool(rng.random() < 0.5)
+        flag = 16 if rev else 0
+        u = rng.random()
+        if u < frac_supp:
+            flag |= 0x800 if rng.random() < 0.5 else 0x100
+        fwd = revcomp(seq) if rev else seq
+        Lq = len(seq)
+        # methylation level of forward offset k: depends on the reference neighbourhood (blocks of 400 bp)
+        def level(k, pos=pos, rev=rev, Lq=Lq, tid=tid):
+            g = pos + (Lq - 1 - k if rev else k)
+            return (0.85, 0.1, 0.5)[((g // 400) + tid) % 3]
+        mm, ml = (None, None) if rng.random() < frac_no_mods else _call_like_mods(fwd, rng, level)
+        reads.append(AlignedRead(f"aln{i}", flag, tid, pos, int(rng.integers(0, 61)), cigar, seq, mm, ml))
+    reads.sort(key=lambda r: (r.tid, r.pos))
+    n_un = int(n_reads * frac_unmapped)
+    for i in range(n_un):                  # unmapped records carry tags too; pileup ignores them
+        s = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 500))
+        mm, ml = _call_like_mods(s, rng, lambda k: 0.5)
+        reads.append(AlignedRead(f"un{i}", 4, -1, -1, 0, [], s, mm, ml))
+    return reads

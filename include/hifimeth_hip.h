@@ -125,6 +125,73 @@ int hm_get_stamps(hm_engine_t* e, uint64_t* out, int cap);
 int hm_get_timing(hm_engine_t* e, hm_timing_t* t);
 int hm_reset_timing(hm_engine_t* e);
 
+/* ==== `hifimeth pileup`: per-locus methylation frequencies ========================
+ * Replaces the body of s_genomic_methy_freq_thread + the counting loop of s_compute_methy_freq
+ * (src/app/hifimeth/pileup.cpp:208-353, 514-560) and the classes they drive:
+ *   BamMapInfo::init / cigar_to_alignment   (src/corelib/bam_info.cpp:262-439)     -> hm_pileup_submit_read
+ *   extract_chh_mapped_samples              (src/corelib/5mc_motif_finder.cpp:104-144)
+ *   CpG / CHG loops                         (pileup.cpp:292-335)                     -> hm_pileup_run
+ *   3 x 256 probability histograms          (pileup.cpp:237-272)                     -> hm_pileup_histograms
+ *   per-locus pcov / ncov / motif           (pileup.cpp:519-560)                     -> hm_pileup_count
+ *   rows of <prefix>.<ctx>.cov.bed          (pileup.cpp:562-590)                     -> hm_pileup_fetch_loci
+ * The whole genome's counters stay resident in HBM (12 B per reference base) and the projected calls wait in
+ * HBM (12 B each) until the thresholds are known -- the reference spills them to a temporary file instead.
+ * MM/ML parsing and BED text formatting stay on the host (hm_bam.h).                                           */
+typedef struct hm_pileup hm_pileup_t;
+
+/* BaseModInfo (src/corelib/bam_mod_parser.hpp): one (position, code) of the MM lists with its ML byte */
+typedef struct {
+    int32_t qoff;       /* forward-strand (original read orientation) offset */
+    uint8_t strand;     /* 0 '+', 1 '-'                                      */
+    char unmod_base;
+    char code;          /* 'm' = 5mC; other codes only enter the histograms  */
+    uint8_t prob;
+} hm_mod_t;
+
+/* one covered locus = one BED row: chrom, soff, soff+1, 100*pcov/(pcov+ncov), pcov, ncov */
+typedef struct {
+    int64_t gpos;       /* offset into the concatenated reference (sequence offset + soff) */
+    int32_t pcov, ncov;
+    uint32_t motif;     /* 0 CpG, 1 CHG, 2 CHH: class of the locus' last record in BAM order */
+    uint32_t reserved;
+} hm_locus_t;
+
+int hm_pileup_create(hm_pileup_t** out, int device);
+void hm_pileup_destroy(hm_pileup_t* p);
+const char* hm_pileup_last_error(const hm_pileup_t* p); /* p may be NULL: error of a failed create */
+/* options: "min_mapq" (-q, default 0), "min_pi" (-f, default 0.0) */
+int hm_pileup_set_option(hm_pileup_t* p, const char* key, double value);
+/* HbnDatabase: n_seqs upper-cased sequences back to back in `bases` (seq_len[i] bytes each).  Allocates and
+ * zeroes the per-locus planes unless hm_pileup_use_planes was called before. */
+int hm_pileup_set_reference(hm_pileup_t* p, int32_t n_seqs, const int64_t* seq_len, const char* bases);
+/* Count into caller-owned DEVICE planes of total-reference-length elements (int32 pcov, int32 ncov, uint32 key),
+ * e.g. torch tensors that a RCCL reduce-scatter will consume.  The caller zeroes them. */
+int hm_pileup_use_planes(hm_pileup_t* p, void* pcov, void* ncov, void* key);
+int hm_pileup_planes(hm_pileup_t* p, void** pcov, void** ncov, void** key, int64_t* n_loci);
+/* One mapped record: `order` = its index in the BAM (decides the motif of a locus hit by two classes), `sid` =
+ * index into the reference sequences, SEQ 4-bit packed and CIGAR as the BAM record stores them, `mods` = its
+ * parsed MM/ML lists.  Returns 1 if staged, 0 if the record contributes nothing (unmapped, no mods), < 0 on
+ * error (illegal base nibble, alignment running past the read or the reference sequence). */
+int hm_pileup_submit_read(hm_pileup_t* p, uint32_t order, int32_t flag, int32_t sid, int64_t pos, int32_t mapq,
+                          int32_t l_qseq, const uint8_t* seq4, int32_t n_cigar, const uint32_t* cigar,
+                          int64_t n_mods, const hm_mod_t* mods);
+/* histograms + projection of the staged records; the projected calls are appended to the HBM-resident list */
+int hm_pileup_run(hm_pileup_t* p);
+int64_t hm_pileup_num_records(hm_pileup_t* p);
+/* bins[ctx*256 + scaled_prob], accumulated over all runs; hm_pileup_add_histograms adds counts from elsewhere */
+int hm_pileup_histograms(hm_pileup_t* p, uint64_t* bins768);
+/* debug / tests: D2H of the projected calls (unordered): gpos, prob, motif, order */
+int64_t hm_pileup_fetch_records(hm_pileup_t* p, int64_t* gpos, uint8_t* prob, uint8_t* motif, uint32_t* order,
+                                int64_t cap);
+/* zero-free accumulate of all resident records into the planes with the given per-context thresholds
+ * (prob >= thr -> pcov else ncov; key = max(order << 2 | motif)); then drops the records */
+int hm_pileup_count(hm_pileup_t* p, const uint8_t thr[3]);
+/* covered loci (pcov + ncov > 0) of planes[lo, hi) in ascending order; planes NULL = the engine's own, else
+ * DEVICE pointers whose element 0 is locus `plane_base`.  Returns the number of loci (may exceed cap: then
+ * nothing is written). */
+int64_t hm_pileup_fetch_loci(hm_pileup_t* p, const void* pcov, const void* ncov, const void* key,
+                             int64_t plane_base, int64_t lo, int64_t hi, hm_locus_t* out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,33 @@ def record(name: str, flag: int, seq4: np.ndarray, l_seq: int, aux: bytes) -> by
     return struct.pack("<I", len(body)) + body
 
 
+def aligned_to_bam(path, genome, reads, sort_order="coordinate", level: int = 6):
+    """hifimeth_amd.synth.AlignedRead objects -> mapped mod-BAM (MM/ML/MN tags), reference list from `genome`."""
+    text = f"@HD\tVN:1.6\tSO:{sort_order}\n" + "".join(f"@SQ\tSN:{n}\tLN:{len(s)}\n" for n, s in genome)
+    parts = [b"BAM\1" + struct.pack("<I", len(text)) + text.encode() + struct.pack("<I", len(genome))]
+    for n, s in genome:
+        nm = n.encode() + b"\0"
+        parts.append(struct.pack("<I", len(nm)) + nm + struct.pack("<I", len(s)))
+    for r in reads:
+        aux = aux_Z("RG", "rg0")
+        if r.mm is not None:
+            aux += aux_Z("MM", r.mm) + aux_B("ML", np.asarray(r.ml, np.uint8)) + aux_i("MN", r.l_qseq)
+        qn = r.name.encode() + b"\0"
+        cig = r.cigar_u32()
+        core = struct.pack("<iiBBHHHiiii", r.tid, r.pos, len(qn), r.mapq, 4680, len(cig), r.flag, r.l_qseq, -1, -1, 0)
+        body = core + qn + cig.astype("<u4").tobytes() + bytes(r.seq4) + b"\xff" * r.l_qseq + aux
+        parts.append(struct.pack("<I", len(body)) + body)
+    write_bgzf(path, b"".join(parts), level=level)
+
+
+def write_fasta(path, genome, width: int = 60):
+    with open(path, "w") as f:
+        for n, s in genome:
+            f.write(f">{n} synthetic\n")
+            for i in range(0, len(s), width):
+                f.write(s[i:i + width] + "\n")
+
+
 def reads_to_bam(path, reads, header_text="@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n", extra_aux=None, level: int = 6):
     """reads: hifimeth_amd.synth.Read objects -> unaligned PacBio-style BAM with fi/fp/ri/rp (+ a few other tags)."""
     parts = [b"BAM\1" + struct.pack("<I", len(header_text)) + header_text.encode() + struct.pack("<I", 0)]

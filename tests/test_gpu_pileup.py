@@ -1,0 +1,194 @@
+"""GPU parity of the `pileup` row: histograms, projected calls, per-locus counters and BED
+text of the HIP path (through the hm_pileup_* C ABI) against the CPU oracle (oracle/pileup_oracle.py), bit-exact."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ROOT, "hifimeth_amd", "bin", "hifimeth-hip")
+
+
+@pytest.fixture(scope="module")
+def P():
+    from oracle import pileup_oracle
+    return pileup_oracle
+
+
+def _as_dict(r):
+    return dict(flag=r.flag, tid=r.tid, pos=r.pos, mapq=r.mapq, cigar=r.cigar, seq=r.seq, mm=r.mm, ml=r.ml)
+
+
+def _data(n=60, eqx=True, seed=7, err=0.01, median_len=1500, length=12000):
+    from hifimeth_amd.synth import synth_alignments, synth_genome
+    genome = synth_genome(n_chr=3, length=length, seed=seed)
+    return genome, synth_alignments(genome, n, seed=seed + 1, median_len=median_len, err=err, eqx=eqx)
+
+
+def _run(genome, reads, batch=16, **kw):
+    from hifimeth_amd.pileup import MethylationPileup
+    pu = MethylationPileup(genome, **kw)
+    for i, r in enumerate(reads):
+        pu.add(r)
+        if (i + 1) % batch == 0:
+            pu.flush()                    # several batches: records accumulate in HBM across runs
+    pu.flush()
+    return pu
+
+
+def _check(P, genome, reads, pu, want, thresholds=None):
+    off = pu.offsets
+    bins = pu.histograms()
+    assert (bins == want["bins"]).all()
+    g, p, m, o = pu.records()
+    order = {id(r): i for i, r in enumerate(reads)}
+    exp = sorted((int(off[sid] + soff), prob, motif) for sid, soff, prob, motif in want["records"])
+    assert sorted(zip(g.tolist(), p.tolist(), m.tolist())) == exp
+    thr = pu.resolve_thresholds(bins) if thresholds is None else thresholds
+    assert thr == want["thresholds"]
+    pu.count(thr)
+    assert pu.num_records() == 0
+    loci = pu.loci()
+    assert [(int(l["gpos"]), int(l["pcov"]), int(l["ncov"]), int(l["motif"])) for l in loci] == \
+        [(int(off[sid] + soff), pc, nc, mo) for sid, soff, pc, nc, mo in want["loci"]]
+    assert pu.bed(loci) == want["bed"]
+    return loci
+
+
+@pytest.mark.parametrize("eqx", [True, False])
+def test_pileup_matches_oracle(P, eqx):
+    genome, reads = _data(eqx=eqx)
+    want = P.pileup([_as_dict(r) for r in reads], genome)
+    assert len(want["records"]) > 10000 and (want["bins"].sum(1) > 0).all()
+    pu = _run(genome, reads)
+    loci = _check(P, genome, reads, pu, want)
+    # per-sequence fetch (what the CLI does) concatenates to the whole
+    parts = [pu.loci(int(pu.offsets[s]), int(pu.offsets[s + 1])) for s in range(len(genome))]
+    assert (np.concatenate(parts) == loci).all()
+    pu.close()
+
+
+def test_pileup_filters(P):
+    genome, reads = _data(n=40, err=0.03)
+    recs = [_as_dict(r) for r in reads]
+    for kw in (dict(min_mapq=30), dict(min_pi=97.5), dict(min_mapq=10, min_pi=96.9)):
+        want = P.pileup(recs, genome, **kw)
+        base = P.pileup(recs, genome)
+        assert 0 < len(want["records"]) < len(base["records"])
+        assert (want["bins"] == base["bins"]).all()          # the filters come after the histograms (pileup.cpp:274)
+        pu = _run(genome, reads, **kw)
+        _check(P, genome, reads, pu, want)
+        pu.close()
+
+
+def test_pileup_explicit_thresholds_and_low_error(P):
+    genome, reads = _data(n=30, err=0.0, seed=19)
+    want = P.pileup([_as_dict(r) for r in reads], genome, thresholds=[200, 60, 128])
+    pu = _run(genome, reads, batch=1000)
+    _check(P, genome, reads, pu, want, thresholds=[200, 60, 128])
+    pu.close()
+
+
+def test_pileup_motif_conflict_follows_bam_order(P):
+    """reference 'CGG': forward reads vote CpG at the C, reverse reads vote CpG at the C and CHG (their own CCG) at
+    the same locus; the locus' file is decided by its last record in BAM order (the reference's own result depends on
+    thread timing there)."""
+    from hifimeth_amd.synth import AlignedRead, revcomp
+    chrom = ("AT" * 20) + "ACGGTTACGGA" + ("TA" * 20)
+    genome = [("c", chrom)]
+    L = len(chrom)
+
+    def read(flag, name):
+        seq = chrom
+        fwd = revcomp(seq) if flag & 16 else seq
+        cs = [i for i, ch in enumerate(fwd) if ch == "C"]
+        mm = "C+m" + "".join(",0" for _ in cs) + ";"
+        return AlignedRead(name, flag, 0, 0, 60, [("M", L)], seq, mm, np.full(len(cs), 250, np.uint8))
+    for flags in ((0, 16), (16, 0), (16, 16, 0, 0)):
+        reads = [read(f, f"r{i}") for i, f in enumerate(flags)]
+        want = P.pileup([_as_dict(r) for r in reads], genome)
+        conflict = [l for l in want["loci"] if chrom[l[1]:l[1] + 3] == "CGG"]
+        assert conflict and all(l[4] == (1 if flags[-1] == 16 else 0) for l in conflict)
+        pu = _run(genome, reads)
+        _check(P, genome, reads, pu, want)
+        pu.close()
+
+
+def test_pileup_submit_errors():
+    from hifimeth_amd import HifimethError
+    from hifimeth_amd.pileup import MethylationPileup
+    from hifimeth_amd.synth import AlignedRead
+    genome = [("c", "ACGT" * 50)]
+    pu = MethylationPileup(genome)
+    ok = AlignedRead("a", 0, 0, 0, 60, [("M", 40)], "ACGT" * 10, "C+m,0;", np.array([200], np.uint8))
+    assert pu.add(ok) == 1
+    assert pu.add(AlignedRead("u", 4, -1, -1, 0, [], "ACGT" * 10, "C+m,0;", np.array([200], np.uint8))) == 0
+    assert pu.add(AlignedRead("n", 0, 0, 0, 60, [("M", 40)], "ACGT" * 10, None, None)) == 0
+    with pytest.raises(HifimethError, match="past the end of the reference"):
+        pu.add(AlignedRead("b", 0, 0, 180, 60, [("M", 40)], "ACGT" * 10, "C+m,0;", np.array([200], np.uint8)))
+    with pytest.raises(HifimethError, match="more bases than SEQ"):
+        pu.add(AlignedRead("c", 0, 0, 0, 60, [("M", 44)], "ACGT" * 10, "C+m,0;", np.array([200], np.uint8)))
+    with pytest.raises(HifimethError, match="sequence index"):
+        pu.add(AlignedRead("d", 0, 3, 0, 60, [("M", 40)], "ACGT" * 10, "C+m,0;", np.array([200], np.uint8)))
+    pu.flush()
+    assert pu.num_records() == 1
+    pu.close()
+
+
+def test_pileup_external_planes_and_rank_slices(P):
+    """the multi-GPU layout on one GPU: count into caller-owned (torch) planes padded to world * chunk, then read each
+    rank's slice back through hm_pileup_fetch_loci with plane_base -- what every rank does after the reduce-scatter."""
+    import torch
+    from hifimeth_amd.pileup import locus_ranges, reduce_scatter_planes
+    genome, reads = _data(n=30)
+    want = P.pileup([_as_dict(r) for r in reads], genome)
+    n_loci = sum(len(s) for _, s in genome)
+    world = 4
+    ranges = locus_ranges(n_loci, world)
+    chunk = ranges[0][1] - ranges[0][0]
+    planes = [torch.zeros(world * chunk, dtype=torch.int32, device="cuda") for _ in range(3)]
+    pu = _run(genome, reads, planes=planes)
+    pu.count(pu.resolve_thresholds(pu.histograms()))
+    torch.cuda.synchronize()
+    rows = []
+    for r, (lo, hi) in enumerate(ranges):
+        sl = [t[r * chunk:(r + 1) * chunk] for t in planes]
+        got = pu.loci(0, hi - lo, planes=sl, plane_base=lo)
+        rows += [(int(l["gpos"]), int(l["pcov"]), int(l["ncov"]), int(l["motif"])) for l in got]
+    off = pu.offsets
+    assert rows == [(int(off[sid] + soff), pc, nc, mo) for sid, soff, pc, nc, mo in want["loci"]]
+
+    class _One:                      # world of one: the exchange is the identity
+        @staticmethod
+        def is_initialized():
+            return False
+    pc, nc, key, base = reduce_scatter_planes(_One, *planes)
+    assert base == 0 and pc.data_ptr() == planes[0].data_ptr()
+    pu.close()
+
+
+def test_cli_pileup_end_to_end(P, tmp_path):
+    from bamutil import aligned_to_bam, write_fasta
+    genome, reads = _data(n=80, seed=31)
+    bam, fa, prefix = str(tmp_path / "mod.bam"), str(tmp_path / "ref.fa"), str(tmp_path / "out")
+    aligned_to_bam(bam, genome, reads)
+    write_fasta(fa, genome)
+    r = subprocess.run([CLI, "pileup", "-t", "4", "-b", "25", fa, bam, prefix], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = P.pileup([_as_dict(x) for x in reads], genome)
+    for c in ("CpG", "CHG", "CHH"):
+        assert open(f"{prefix}.{c}.cov.bed").read() == want["bed"][c]
+        assert f"{c} samples: " in r.stderr
+    # filters on the command line
+    r = subprocess.run([CLI, "pileup", "-q", "20", "-f", "98.5", fa, bam, prefix + "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = P.pileup([_as_dict(x) for x in reads], genome, min_mapq=20, min_pi=98.5)
+    for c in ("CpG", "CHG", "CHH"):
+        assert open(f"{prefix}2.{c}.cov.bed").read() == want["bed"][c]
+    # unsorted / unmapped input is refused like the reference does (pileup.cpp:438-459)
+    aligned_to_bam(bam, genome, reads, sort_order="unknown")
+    r = subprocess.run([CLI, "pileup", fa, bam, prefix + "3"], capture_output=True, text=True)
+    assert r.returncode == 1 and "BAM is not sorted" in r.stderr

@@ -13,7 +13,10 @@ GPU box never needs the reference.  Three sources, each the reference's own code
                  (torch.jit.load on CPU).  CHG.pt holds a different checkpoint than CHG.onnx
                   and is not used.
 
-usage: python tools/make_golden.py [/root/reference]
+  align.json     alignment columns, identity and mapped CpG/CHG/CHH samples from the reference's BamMapInfo and
+                 5mc_motif_finder.cpp (oracle/_ref/ref_align) -- pins the pileup oracle's projection
+
+usage: python tools/make_golden.py [/root/reference [align]]
 """
 import json
 import os
@@ -188,10 +191,46 @@ def make_config_goldens():
     np.savez_compressed(os.path.join(GOLD, "config1_calls.npz"), **out)
 
 
+def make_align():
+    """align.json: the reference's own BamMapInfo::init / cigar_to_alignment (src/corelib/bam_info.cpp:262-439) and
+    extract_{cpg,chg,chh}_mapped_samples (src/corelib/5mc_motif_finder.cpp), built by oracle/ref_build into
+    oracle/_ref/ref_align, run on synthetic alignments (=/X and M CIGARs, soft clips, both strands, an N op, a
+    leading hard clip, an unmapped record)."""
+    from hifimeth_amd.synth import AlignedRead, synth_alignments, synth_genome
+    from oracle import pileup_oracle as P
+    genome = synth_genome(n_chr=2, length=2500, seed=17)
+    reads = synth_alignments(genome, 8, seed=23, median_len=600, err=0.03, eqx=True, frac_unmapped=0.13)
+    reads += synth_alignments(genome, 6, seed=29, median_len=500, err=0.03, eqx=False, frac_unmapped=0)
+    chrom = genome[0][1]
+    reads.append(AlignedRead("skipN", 0, 0, 100, 60, [("H", 7), ("M", 50), ("N", 40), ("M", 60), ("P", 2), ("M", 5), ("S", 4)],
+                             chrom[100:150] + chrom[190:250] + chrom[250:255] + "ACGT", None, None))
+    fa = "/tmp/_golden_align.fa"
+    with open(fa, "w") as f:
+        f.write("! comment line\n")
+        for n, sq in genome:
+            f.write(f">{n} some description\n")
+            for i in range(0, len(sq), 70):
+                f.write(sq[i:i + 70].lower() if (i // 70) % 5 == 0 else sq[i:i + 70])
+                f.write("\n")
+    assert P.load_fasta(fa) == genome
+    out = P.ref_align(fa, [(r.flag, max(r.tid, 0), max(r.pos, 0), r.cigar_string() if r.cigar else "1M", r.seq) for r in reads])
+    recs = []
+    for r, d in zip(reads, out):
+        recs.append(dict(flag=r.flag, tid=r.tid, pos=r.pos, cigar=r.cigar_string(), seq=r.seq, ref=d))
+    json.dump(dict(genome=genome, reads=recs), open(os.path.join(GOLD, "align.json"), "w"))
+    os.remove(fa)
+    print(f"align.json: {len(recs)} records, {sum(d is not None for d in out)} mapped, "
+          f"{sum(len(d['chh']) for d in out if d)} CHH samples")
+
+
 if __name__ == "__main__":
     if not O.ref_scan_available():
         raise SystemExit("build oracle/_ref first: make -C oracle")
+    if len(sys.argv) > 2 and sys.argv[2] == "align":      # only the pileup fixtures
+        make_align()
+        raise SystemExit(0)
     make_scan()
     w = make_windows()
     make_cnn(w)
     make_config_goldens()
+    make_align()
