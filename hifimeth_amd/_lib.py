@@ -46,6 +46,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hifimeth_amd has no CPU fallback)")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  If this library were loaded
+    # first, a later `import torch` would bring a SECOND HIP runtime into the process and torch would then see no
+    # GPU; importing torch first makes the loader resolve our NEEDED libamdhip64.so.7 to the copy already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, cp = C.c_void_p, C.c_int32, C.c_int64, C.c_char_p
     sig = {

@@ -150,9 +150,9 @@ __global__ __launch_bounds__(TPB) void mods_kernel(const PMod* __restrict__ mods
         if (h[i]) atomicAdd(&bins[i], (unsigned long long)h[i]);
 }
 
-// run holding global column c: largest r with col0[r] <= c
-__device__ __forceinline__ int find_run(const int64_t* __restrict__ col0, int n_runs, int64_t c) {
-    int lo = 0, hi = n_runs;  // col0[lo] <= c < col0[hi]
+// run holding global column c: largest r in [lo, hi) with col0[r] <= c
+__device__ __forceinline__ int find_run(const int64_t* __restrict__ col0, int n_runs, int64_t c, int lo = 0, int hi = -1) {
+    if (hi < 0) hi = n_runs;  // col0[lo] <= c < col0[hi]
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (col0[mid] <= c) lo = mid; else hi = mid;
@@ -184,68 +184,93 @@ __global__ __launch_bounds__(TPB) void identity_kernel(const PRun* __restrict__ 
     }
 }
 
-// append one record per lane with `pred`: one atomic per wavefront
-__device__ __forceinline__ void append_record(bool pred, PRec rec, PRec* __restrict__ out,
-                                              unsigned long long* __restrict__ counter) {
+// append one record per lane with `pred` to the workgroup's LDS stage: one LDS atomic per wavefront
+__device__ __forceinline__ void stage_record(bool pred, const PRec& rec, PRec* __restrict__ stage, int* __restrict__ n_stage) {
     const unsigned long long b = __ballot(pred);
     if (!b) return;
     const int lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)b) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(b));
+    int base = 0;
+    if (lane == leader) base = atomicAdd(n_stage, __popcll(b));
     base = __shfl(base, leader);
-    if (pred) out[base + __popcll(b & ((1ull << lane) - 1ull))] = rec;
+    if (pred) stage[base + __popcll(b & ((1ull << lane) - 1ull))] = rec;
 }
 
 // ---- projection (pileup.cpp:286-347, 5mc_motif_finder.cpp:104-144) -----------------------------------------
+// A workgroup walks PTILE consecutive columns, stages its records in LDS and appends them to the global list with
+// ONE atomic (same-address atomics from every wavefront serialise in L2 and dominated an earlier version).
+constexpr int PTILE = 2048;
+
 __global__ __launch_bounds__(TPB) void project_kernel(const PRun* __restrict__ runs, const int64_t* __restrict__ col0,
                                                        int n_runs, int64_t n_cols, const PRead* __restrict__ reads,
                                                        const uint8_t* __restrict__ slab, const char* __restrict__ ref,
                                                        const uint32_t* __restrict__ plane,
                                                        const int32_t* __restrict__ matches, double min_pi,
                                                        PRec* __restrict__ out, unsigned long long* __restrict__ counter) {
-    const int64_t c = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    bool e0 = false, e1 = false;  // a column yields at most two records (CpG + the reverse-strand CGG of CHG)
-    PRec r0{}, r1{};
-    if (c < n_cols) {
-        const int ri = find_run(col0, n_runs, c);
-        const PRun run = runs[ri];
-        const int o = (int)(c - col0[ri]);
-        const int rem = run.len - o;
-        const PRead rd = reads[run.read];
-        bool live = rd.pass && rem >= 2;
-        if (live && min_pi > 0.0) live = !(100.0 * matches[run.read] / rd.as_size < min_pi);
-        if (live) {
-            const int qp = run.q0 + o, L = rd.l_qseq;
-            const int64_t g = run.g0 + o;
-            const char q0 = stored_base(slab, rd, qp), q1 = stored_base(slab, rd, qp + 1);
-            const char s0 = ref[g], s1 = ref[g + 1];
-            char q2 = '-', s2 = '*';
-            if (rem >= 3) { q2 = stored_base(slab, rd, qp + 2); s2 = ref[g + 2]; }
-            const bool eq3 = rem >= 3 && q0 == s0 && q1 == s1 && q2 == s2;
-            auto look = [&](int qoff, int64_t soff, uint32_t motif, bool& e, PRec& r) {
-                const uint32_t v = plane[rd.plane_off + qoff];
-                if (v & 0x100u) {
-                    e = true;
-                    r.glo = (uint32_t)soff;
-                    r.hi = (uint32_t)((uint64_t)soff >> 32) | ((v & 255u) << 8) | (motif << 16);
-                    r.order = rd.order;
+    __shared__ PRec stage[2 * PTILE];  // a column yields at most two records (CpG + the reverse-strand CGG of CHG)
+    __shared__ int n_stage;
+    __shared__ int run_range[2];  // runs touched by this tile: the per-column search starts from here
+    __shared__ unsigned long long out_base;
+    if (threadIdx.x == 0) n_stage = 0;
+    if (threadIdx.x < 2) {
+        const int64_t c = min((int64_t)blockIdx.x * PTILE + (threadIdx.x ? PTILE - 1 : 0), n_cols - 1);
+        run_range[threadIdx.x] = find_run(col0, n_runs, c) + (int)threadIdx.x;
+    }
+    __syncthreads();
+    const int run_lo = run_range[0], run_hi = run_range[1];
+    for (int it = 0; it < PTILE / TPB; ++it) {
+        const int64_t c = (int64_t)blockIdx.x * PTILE + it * TPB + threadIdx.x;
+        bool e0 = false, e1 = false;
+        PRec r0{}, r1{};
+        if (c < n_cols) {
+            const int ri = find_run(col0, n_runs, c, run_lo, run_hi);
+            const PRun run = runs[ri];
+            const int o = (int)(c - col0[ri]);
+            const int rem = run.len - o;
+            const PRead rd = reads[run.read];
+            bool live = rd.pass && rem >= 2;
+            if (live && min_pi > 0.0) live = !(100.0 * matches[run.read] / rd.as_size < min_pi);
+            if (live) {
+                const int qp = run.q0 + o, L = rd.l_qseq;
+                const int64_t g = run.g0 + o;
+                const char q0 = stored_base(slab, rd, qp), q1 = stored_base(slab, rd, qp + 1);
+                const char s0 = ref[g], s1 = ref[g + 1];
+                char q2 = '-', s2 = '*';
+                if (rem >= 3) { q2 = stored_base(slab, rd, qp + 2); s2 = ref[g + 2]; }
+                const bool eq3 = rem >= 3 && q0 == s0 && q1 == s1 && q2 == s2;
+                auto look = [&](int qoff, int64_t soff, uint32_t motif, bool& e, PRec& r) {
+                    const uint32_t v = plane[rd.plane_off + qoff];
+                    if (v & 0x100u) {
+                        e = true;
+                        r.glo = (uint32_t)soff;
+                        r.hi = (uint32_t)((uint64_t)soff >> 32) | ((v & 255u) << 8) | (motif << 16);
+                        r.order = rd.order;
+                    }
+                };
+                if (q0 == 'C' && q1 == 'G' && s0 == 'C' && s1 == 'G')  // CpG, recorded at the reference C
+                    look(rd.rev ? L - 1 - (qp + 1) : qp, g, 0, e0, r0);
+                if (eq3 && q0 == 'C' && q2 == 'G') {  // CHG: forward reads CCG/CAG/CTG, reverse reads CGG/CAG/CTG
+                    const bool mid = rd.rev ? (q1 == 'G' || q1 == 'A' || q1 == 'T') : (q1 == 'C' || q1 == 'A' || q1 == 'T');
+                    if (mid) look(rd.rev ? L - 1 - (qp + 2) : qp, g, 1, e1, r1);
+                } else if (eq3 && q0 == 'C' && isH(q1) && isH(q2)) {  // CHH on the reference's forward strand
+                    look(rd.rev ? L - 1 - qp : qp, g, 2, e1, r1);
+                } else if (eq3 && isD(q0) && isD(q1) && q2 == 'G') {  // CHH on the reverse strand, recorded at the G
+                    look(rd.rev ? L - 1 - (qp + 2) : qp + 2, g + 2, 2, e1, r1);
                 }
-            };
-            if (q0 == 'C' && q1 == 'G' && s0 == 'C' && s1 == 'G')  // CpG, recorded at the reference C
-                look(rd.rev ? L - 1 - (qp + 1) : qp, g, 0, e0, r0);
-            if (eq3 && q0 == 'C' && q2 == 'G') {  // CHG: forward reads CCG/CAG/CTG, reverse reads CGG/CAG/CTG
-                const bool mid = rd.rev ? (q1 == 'G' || q1 == 'A' || q1 == 'T') : (q1 == 'C' || q1 == 'A' || q1 == 'T');
-                if (mid) look(rd.rev ? L - 1 - (qp + 2) : qp, g, 1, e1, r1);
-            } else if (eq3 && q0 == 'C' && isH(q1) && isH(q2)) {  // CHH on the reference's forward strand
-                look(rd.rev ? L - 1 - qp : qp, g, 2, e1, r1);
-            } else if (eq3 && isD(q0) && isD(q1) && q2 == 'G') {  // CHH on the reverse strand, recorded at the G
-                look(rd.rev ? L - 1 - (qp + 2) : qp + 2, g + 2, 2, e1, r1);
             }
         }
+        stage_record(e0, r0, stage, &n_stage);
+        stage_record(e1, r1, stage, &n_stage);
     }
-    append_record(e0, r0, out, counter);
-    append_record(e1, r1, out, counter);
+    __syncthreads();
+    const int n = n_stage;
+    if (threadIdx.x == 0 && n) out_base = atomicAdd(counter, (unsigned long long)n);
+    __syncthreads();
+    if (n) {  // 12-byte records move as a stream of dwords
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(stage);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(out + out_base);
+        for (int i = threadIdx.x; i < 3 * n; i += TPB) dst[i] = src[i];
+    }
 }
 
 // ---- counting (pileup.cpp:529-557) -------------------------------------------------------------------------
@@ -628,13 +653,13 @@ int hm_pileup_run(hm_pileup_t* p) {
                                p->d_reads.as<PRead>(), p->d_slab.as<uint8_t>(), p->d_plane.as<uint32_t>(),
                                p->d_bins.as<unsigned long long>());
         if (cols > 0) {
-            const int64_t blocks = (cols + TPB - 1) / TPB;
+            const int64_t blocks = (cols + TPB - 1) / TPB, pblocks = (cols + PTILE - 1) / PTILE;
             if (blocks >= (int64_t(1) << 31)) return pfail(p, HM_EINVAL, "batch too large: submit fewer records per hm_pileup_run");
             if (p->min_pi > 0.0)
                 hipLaunchKernelGGL(identity_kernel, dim3((unsigned)blocks), dim3(TPB), 0, st, p->d_runs.as<PRun>(),
                                    p->d_col0.as<int64_t>(), n_runs, cols, p->d_reads.as<PRead>(), p->d_slab.as<uint8_t>(),
                                    p->d_ref.as<char>(), p->d_matches.as<int32_t>());
-            hipLaunchKernelGGL(project_kernel, dim3((unsigned)blocks), dim3(TPB), 0, st, p->d_runs.as<PRun>(),
+            hipLaunchKernelGGL(project_kernel, dim3((unsigned)pblocks), dim3(TPB), 0, st, p->d_runs.as<PRun>(),
                                p->d_col0.as<int64_t>(), n_runs, cols, p->d_reads.as<PRead>(), p->d_slab.as<uint8_t>(),
                                p->d_ref.as<char>(), p->d_plane.as<uint32_t>(), p->d_matches.as<int32_t>(), p->min_pi,
                                p->d_recs.as<PRec>(), p->d_counter.as<unsigned long long>());
