@@ -19,12 +19,17 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(backend: str | None = None):
+def init_process_group(backend: str | None = None, force: bool = False):
     """Initialise torch.distributed from the env (MASTER_ADDR/PORT, RANK, WORLD_SIZE). Returns the
-    module, or None for a single-process run."""
+    module, or None for a single-process run (`force`: build a world of one anyway, to rehearse the collectives)."""
     rank, local_rank, world = env_world()
-    if world <= 1:
+    if world <= 1 and not force:
         return None
+    if world <= 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     import torch
     import torch.distributed as dist
     if backend is None:

@@ -196,12 +196,12 @@ def locus_ranges(n_loci: int, world: int) -> List[Tuple[int, int]]:
 def allreduce_histograms(dist, bins: np.ndarray, device: str = "cpu") -> np.ndarray:
     import torch
     t = torch.from_numpy(bins.astype(np.int64).reshape(-1)).to(device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy().astype(np.uint64).reshape(3, 256)
 
 
-def reduce_scatter_planes(dist, pcov, ncov, key):
+def reduce_scatter_planes(dist, pcov, ncov, key, force: bool = False):
     """-> (pcov, ncov, key, base): this rank's slice of the job-wide planes, `base` = its first locus.
     pcov / ncov are summed, key (order << 2 | motif, < 2^31 so int32 compares like uint32) takes the maximum.
     Planes must be padded to world * chunk elements.  RCCL reduce-scatters; gloo (CPU tests) all-reduces and slices."""
@@ -210,7 +210,7 @@ def reduce_scatter_planes(dist, pcov, ncov, key):
     n = pcov.numel()
     assert n % world == 0
     chunk = n // world
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return pcov, ncov, key, 0
     import torch
     outs = []

@@ -192,3 +192,26 @@ def test_cli_pileup_end_to_end(P, tmp_path):
     aligned_to_bam(bam, genome, reads, sort_order="unknown")
     r = subprocess.run([CLI, "pileup", fa, bam, prefix + "3"], capture_output=True, text=True)
     assert r.returncode == 1 and "BAM is not sorted" in r.stderr
+
+
+@pytest.mark.parametrize("force_collectives", [False, True])
+def test_pileup_dist_driver(P, tmp_path, force_collectives):
+    """python -m hifimeth_amd.pileup_dist on one GPU: plain, and as a world of one over RCCL (all-reduce of the
+    histograms, reduce-scatter of the planes) -- the code path every rank of an N-GPU job runs."""
+    import sys
+    from bamutil import aligned_to_bam, write_fasta
+    genome, reads = _data(n=50, seed=53)
+    bam, fa, prefix = str(tmp_path / "mod.bam"), str(tmp_path / "ref.fa"), str(tmp_path / "out")
+    aligned_to_bam(bam, genome, reads)
+    write_fasta(fa, genome)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if force_collectives:
+        env.update(HM_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, "-m", "hifimeth_amd.pileup_dist", "--slab", "7", fa, bam, prefix],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = P.pileup([_as_dict(x) for x in reads], genome)
+    for c in ("CpG", "CHG", "CHH"):
+        assert open(f"{prefix}.{c}.cov.bed").read() == want["bed"][c]
