@@ -438,21 +438,40 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
     float* hfc = reinterpret_cast<float*>(h1);  // fc1 activations (fp32) reuse buffer 1
     auto wf = [&](int i) { return reinterpret_cast<const half_t*>(W.wfrag_h[i]); };
 
+    // act4 of a group of S sites = S * 600 float4; thread t owns elements t + 512 k.  The next group's elements are
+    // fetched into registers right after the current ones have been split into LDS, so the HBM/L2 latency of the
+    // 77 KB hand-off hides behind the conv5..fc2 work of the current group.
+    constexpr int Q4 = ACT4_FLOATS / 4, NPRE = (S * Q4 + NW * 64 - 1) / (NW * 64);
+    float4 pre[NPRE];
+    auto fetch = [&](int grp) __attribute__((always_inline)) {
+        const int first = grp * S, nvv = min(S, n_sites - first);
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int i = threadIdx.x + k * NW * 64;
+            const int site = i / Q4;
+            pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < S * Q4 && site < nvv) pre[k] = *reinterpret_cast<const float4*>(act4 + (size_t)first * ACT4_FLOATS + (size_t)i * 4);
+        }
+    };
+    if ((int)blockIdx.x * S < n_sites) fetch(blockIdx.x);
     for (int g = blockIdx.x; g * S < n_sites; g += gridDim.x) {
         const int s0 = g * S;
         const int nv = min(S, n_sites - s0);
         // act4 [site][25][96] fp32 -> split planes 0, rows 1..25
-        for (int i = threadIdx.x; i < S * (ACT4_FLOATS / 4); i += NW * 64) {
-            const int site = i / (ACT4_FLOATS / 4), rem = (i - site * (ACT4_FLOATS / 4)) * 4;
-            const int pos = rem / C4_CH, c = rem - pos * C4_CH;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (site < nv) v = *reinterpret_cast<const float4*>(act4 + (size_t)(s0 + site) * ACT4_FLOATS + rem);
-            half4 h, l;
-            split4(f32x4{v.x, v.y, v.z, v.w}, h, l);  // act4 is post-ReLU already: the max() is a no-op
-            const int o = site * T::IN_SS + (pos + 1) * T::RS96 + c;
-            *reinterpret_cast<half4*>(h0 + o) = h;
-            *reinterpret_cast<half4*>(l0 + o) = l;
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int i = threadIdx.x + k * NW * 64;
+            if (i < S * Q4) {
+                const int site = i / Q4, rem = (i - site * Q4) * 4;
+                const int pos = rem / C4_CH, c = rem - pos * C4_CH;
+                half4 h, l;
+                split4(f32x4{pre[k].x, pre[k].y, pre[k].z, pre[k].w}, h, l);  // act4 is post-ReLU already: the max() is a no-op
+                const int o = site * T::IN_SS + (pos + 1) * T::RS96 + c;
+                *reinterpret_cast<half4*>(h0 + o) = h;
+                *reinterpret_cast<half4*>(l0 + o) = l;
+            }
         }
+        if ((g + (int)gridDim.x) * S < n_sites) fetch(g + gridDim.x);
         zero_pad_rows_h<S, T::L4, 96>(h0, l0, T::RS96, T::IN_SS);
         __syncthreads();
 
