@@ -6,10 +6,13 @@
 // histograms and per-locus counting run on the GPU through the hm_pileup_* C ABI.  No temporary file is written:
 // the projected calls stay in HBM until the thresholds are known.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hifimeth_hip.h"
@@ -24,7 +27,7 @@ struct PileupOptions {
     double min_pi = 0.0;  // kMinPi
     int threads = 8;      // kNumThreads
     int device = 0;
-    int read_batch = 4096;
+    int read_batch = 512;
     std::string ref, bam, prefix;
 };
 
@@ -37,7 +40,7 @@ void pileup_usage(const char* exe) {
             "  -f <Alignment identity>\n    Default: 0\n"
             "  -t <CPU threads>\n    Number of CPU threads\n    Default: 8\n"
             "  -d <int>\n    GPU ordinal\n    Default: 0\n"
-            "  -b <int>\n    BAM records per GPU batch\n    Default: 4096\n",
+            "  -b <int>\n    BAM records per GPU batch\n    Default: 512\n",
             exe);
 }
 
@@ -115,6 +118,10 @@ int cmd_pileup(int argc, char** argv) {
                     "Genomic reference: %s\nmod-bam: %s\noutput prefix: %s\n\n\n",
             o.min_mapq, o.min_pi, o.threads, o.ref.c_str(), o.bam.c_str(), o.prefix.c_str());
 
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t_start = clk::now();
+    double t_read = 0, t_parse = 0, t_submit = 0, t_gpu = 0;
     BgzfReader in(o.bam, o.threads);
     BamHeader hdr;
     std::string err;
@@ -138,46 +145,85 @@ int cmd_pileup(int argc, char** argv) {
     if (fa.names.empty()) { fprintf(stderr, "ERROR: no sequence in %s\n", o.ref.c_str()); hm_pileup_destroy(pe); return EXIT_FAILURE; }
     if (hm_pileup_set_reference(pe, (int32_t)fa.names.size(), fa.length.data(), fa.bases.data()) != HM_OK) return die("reference");
 
-    std::vector<BamRecord> batch((size_t)o.read_batch);
-    std::vector<std::vector<BaseMod>> mods((size_t)o.read_batch);
-    std::vector<std::string> perr((size_t)o.read_batch);
-    uint64_t n_records = 0;
-    bool more = true;
-    while (more) {
+    // Two batches in flight: a producer thread inflates + parses batch k+1 (parse_mods over `threads` workers) while
+    // this thread stages batch k and runs the GPU.
+    struct Batch {
+        std::vector<BamRecord> recs;
+        std::vector<std::vector<BaseMod>> mods;
+        std::vector<std::string> perr;
         int n = 0;
-        while (n < o.read_batch && (more = read_record(in, batch[(size_t)n], err))) ++n;
-        if (!err.empty()) { fprintf(stderr, "ERROR: Could not read BAM record: %s\n", err.c_str()); hm_pileup_destroy(pe); return EXIT_FAILURE; }
-        parallel_run(n, o.threads, [&](int k) {
-            mods[(size_t)k].clear();
-            perr[(size_t)k].clear();
-            if (!parse_mods(batch[(size_t)k], mods[(size_t)k], perr[(size_t)k])) mods[(size_t)k].clear();
+        bool more = true;
+        std::string err;
+        double t_read = 0, t_parse = 0;
+    };
+    Batch bb[2];
+    for (Batch& b : bb) {
+        b.recs.resize((size_t)o.read_batch);
+        b.mods.resize((size_t)o.read_batch);
+        b.perr.resize((size_t)o.read_batch);
+    }
+    auto produce = [&](Batch& b) {
+        auto t0 = clk::now();
+        b.n = 0;
+        b.err.clear();
+        while (b.n < o.read_batch && (b.more = read_record(in, b.recs[(size_t)b.n], b.err))) ++b.n;
+        auto t1 = clk::now();
+        parallel_run(b.n, o.threads, [&](int k) {
+            b.mods[(size_t)k].clear();
+            b.perr[(size_t)k].clear();
+            if (!parse_mods(b.recs[(size_t)k], b.mods[(size_t)k], b.perr[(size_t)k])) b.mods[(size_t)k].clear();
         });
-        for (int k = 0; k < n; ++k) {
-            const BamRecord& r = batch[(size_t)k];
+        b.t_read = secs(t0, t1);
+        b.t_parse = secs(t1, clk::now());
+    };
+    uint64_t n_records = 0;
+    int cur = 0;
+    produce(bb[0]);
+    std::vector<uint32_t> cig;
+    while (true) {
+        Batch& b = bb[cur];
+        t_read += b.t_read;
+        t_parse += b.t_parse;
+        if (!b.err.empty()) { fprintf(stderr, "ERROR: Could not read BAM record: %s\n", b.err.c_str()); hm_pileup_destroy(pe); return EXIT_FAILURE; }
+        std::thread producer;
+        if (b.more) producer = std::thread(produce, std::ref(bb[cur ^ 1]));
+        auto fail_out = [&]() { if (producer.joinable()) producer.join(); hm_pileup_destroy(pe); return EXIT_FAILURE; };
+        auto t2 = clk::now();
+        for (int k = 0; k < b.n; ++k) {
+            const BamRecord& r = b.recs[(size_t)k];
             const uint64_t order = n_records++;
-            if (!perr[(size_t)k].empty()) {
-                fprintf(stderr, "ERROR at parsing read %s\n%s\n", reinterpret_cast<const char*>(r.data.data() + 32), perr[(size_t)k].c_str());
-                hm_pileup_destroy(pe);
-                return EXIT_FAILURE;
+            if (!b.perr[(size_t)k].empty()) {
+                fprintf(stderr, "ERROR at parsing read %s\n%s\n", reinterpret_cast<const char*>(r.data.data() + 32), b.perr[(size_t)k].c_str());
+                return fail_out();
             }
-            if (mods[(size_t)k].empty() || (r.flag() & 4)) continue;
+            if (b.mods[(size_t)k].empty() || (r.flag() & 4)) continue;
             const int tid = r.ref_id();
-            if (tid < 0 || tid >= (int)hdr.refs.size()) { fprintf(stderr, "ERROR: mapped record without a reference id\n"); hm_pileup_destroy(pe); return EXIT_FAILURE; }
+            if (tid < 0 || tid >= (int)hdr.refs.size()) { fprintf(stderr, "ERROR: mapped record without a reference id\n"); return fail_out(); }
             if (tid2sid[(size_t)tid] == -2) tid2sid[(size_t)tid] = fa.find(hdr.refs[(size_t)tid].first);
             if (tid2sid[(size_t)tid] < 0) {
                 fprintf(stderr, "ERROR: Sequence name %s does not exist\n", hdr.refs[(size_t)tid].first.c_str());
-                hm_pileup_destroy(pe);
-                return EXIT_FAILURE;
+                return fail_out();
             }
-            std::vector<uint32_t> cig((size_t)r.n_cigar());
+            cig.resize((size_t)r.n_cigar());
             if (!cig.empty()) memcpy(cig.data(), r.cigar_bytes(), 4 * cig.size());
             const int rc = hm_pileup_submit_read(pe, (uint32_t)order, r.flag(), tid2sid[(size_t)tid], r.pos(), r.mapq(), r.l_qseq(),
-                                                 r.seq4(), r.n_cigar(), cig.data(), (int64_t)mods[(size_t)k].size(),
-                                                 mods[(size_t)k].data());
-            if (rc < 0) return die(std::string("read ") + reinterpret_cast<const char*>(r.data.data() + 32));
+                                                 r.seq4(), r.n_cigar(), cig.data(), (int64_t)b.mods[(size_t)k].size(),
+                                                 b.mods[(size_t)k].data());
+            if (rc < 0) {
+                fprintf(stderr, "ERROR: read %s: %s\n", reinterpret_cast<const char*>(r.data.data() + 32), hm_pileup_last_error(pe));
+                return fail_out();
+            }
         }
-        if (hm_pileup_run(pe) != HM_OK) return die("projection");
+        auto t3 = clk::now();
+        t_submit += secs(t2, t3);
+        const int rrc = hm_pileup_run(pe);
+        t_gpu += secs(t3, clk::now());
+        if (producer.joinable()) producer.join();
+        if (rrc != HM_OK) return die("projection");
+        if (!b.more) break;
+        cur ^= 1;
     }
+    const auto t_loop = clk::now();
 
     static uint64_t bins[768];
     if (hm_pileup_histograms(pe, bins) != HM_OK) return die("histograms");
@@ -205,7 +251,8 @@ int cmd_pileup(int argc, char** argv) {
         if (!out[c]) { fprintf(stderr, "ERROR: cannot open %s for writing\n", path.c_str()); hm_pileup_destroy(pe); return EXIT_FAILURE; }
     }
     std::vector<hm_locus_t> loci;
-    std::string text[3];
+    const int fmt_threads = std::max(1, o.threads);
+    std::vector<std::string> text((size_t)fmt_threads * 3);
     int64_t off = 0;
     for (size_t s = 0; s < fa.names.size(); ++s) {
         const int64_t lo = off, hi = off + fa.length[s];
@@ -216,20 +263,31 @@ int cmd_pileup(int argc, char** argv) {
         loci.resize((size_t)n);
         n = hm_pileup_fetch_loci(pe, nullptr, nullptr, nullptr, 0, lo, hi, loci.data(), n);
         if (n < 0) return die("loci");
-        for (auto& t : text) t.clear();
-        char row[256];
-        for (const hm_locus_t& l : loci) {  // pileup.cpp:562-586
-            const int64_t k = l.gpos - lo;
-            const double freq = 100.0 * l.pcov / (l.pcov + l.ncov);
-            const int len = snprintf(row, sizeof row, "\t%lld\t%lld\t%g\t%d\t%d\n", (long long)k, (long long)k + 1, freq, l.pcov, l.ncov);
-            std::string& t = text[l.motif < 3 ? l.motif : 2];
-            t += fa.names[s];
-            t.append(row, (size_t)len);
-        }
+        // rows are formatted by `fmt_threads` workers over contiguous slices and written slice by slice (pileup.cpp:562-590)
+        parallel_run(fmt_threads, fmt_threads, [&](int w) {
+            for (int c = 0; c < 3; ++c) text[(size_t)w * 3 + c].clear();
+            const size_t a = (size_t)n * w / fmt_threads, b = (size_t)n * (w + 1) / fmt_threads;
+            char row[256];
+            for (size_t i = a; i < b; ++i) {
+                const hm_locus_t& l = loci[i];
+                const int64_t k = l.gpos - lo;
+                const double freq = 100.0 * l.pcov / (l.pcov + l.ncov);
+                const int len = snprintf(row, sizeof row, "\t%lld\t%lld\t%g\t%d\t%d\n", (long long)k, (long long)k + 1, freq, l.pcov, l.ncov);
+                std::string& t = text[(size_t)w * 3 + (l.motif < 3 ? l.motif : 2)];
+                t += fa.names[s];
+                t.append(row, (size_t)len);
+            }
+        });
         for (int c = 0; c < 3; ++c)
-            if (!text[c].empty()) fwrite(text[c].data(), 1, text[c].size(), out[c]);
+            for (int w = 0; w < fmt_threads; ++w) {
+                const std::string& t = text[(size_t)w * 3 + c];
+                if (!t.empty()) fwrite(t.data(), 1, t.size(), out[c]);
+            }
     }
     for (FILE* f : out) fclose(f);
     hm_pileup_destroy(pe);
+    fprintf(stderr, "## %llu records in %.2f s: [producer thread: BAM read %.2f s, MM/ML parse %.2f s] overlapped with "
+                    "[staging %.2f s, GPU projection %.2f s]; thresholds + count + BED %.2f s\n",
+            (unsigned long long)n_records, secs(t_start, clk::now()), t_read, t_parse, t_submit, t_gpu, secs(t_loop, clk::now()));
     return 0;
 }

@@ -513,52 +513,70 @@ bool parse_mods(const BamRecord& r, std::vector<BaseMod>& mods, std::string& err
         probs[i] = (uint8_t)v;
     }
     if (probs.empty()) return true;
-    const std::string mms(reinterpret_cast<const char*>(mm.payload));
-    if (mms.empty() || mms.back() != ';') { err = "The MM aux tag must end with ';'"; return false; }
+    const char* mms = reinterpret_cast<const char*>(mm.payload);
+    const size_t mml = strlen(mms);
+    if (mml == 0 || mms[mml - 1] != ';') { err = "The MM aux tag must end with ';'"; return false; }
     const int L = r.l_qseq();
+    // forward-strand sequence, decoded once (get_bam_fwd_strand_base for every offset, bam_info.cpp:224-233)
+    thread_local std::string fwd;
+    fwd.resize((size_t)L);
+    {
+        const uint8_t* s4 = r.seq4();
+        static const char dec[17] = "NACNGNNNTNNNNNNN", cmp[17] = "NTGNCNNNANNNNNNN";
+        if (r.flag() & 16)
+            for (int k = 0; k < L; ++k) {
+                const int i = L - 1 - k;
+                fwd[(size_t)k] = cmp[(s4[i >> 1] >> ((~i & 1) << 2)) & 15];
+            }
+        else
+            for (int k = 0; k < L; ++k) fwd[(size_t)k] = dec[(s4[k >> 1] >> ((~k & 1) << 2)) & 15];
+    }
     size_t pi = 0;
-    for (size_t i = 0; i < mms.size();) {
-        size_t j = mms.find(';', i);
-        const std::string s = mms.substr(i, j - i + 1);  // one edit series incl. ';'
+    for (size_t i = 0; i < mml;) {
+        const char* sc = static_cast<const char*>(memchr(mms + i, ';', mml - i));
+        const size_t j = (size_t)(sc - mms);
+        const char* s = mms + i;          // one edit series incl. ';'
+        const size_t sl = j - i + 1;
         i = j + 1;
-        if (s.size() < 4) { err = "Corrupted edit series " + s; return false; }
+        auto series = [&]() { return std::string(s, sl); };
+        if (sl < 4) { err = "Corrupted edit series " + series(); return false; }
         const char ub = s[0];
-        if (!strchr("CGTAUN", ub) || (s[1] != '+' && s[1] != '-')) { err = "Unrecognised base or strand in edit series " + s; return false; }
+        if (!strchr("CGTAUN", ub) || (s[1] != '+' && s[1] != '-')) { err = "Unrecognised base or strand in edit series " + series(); return false; }
         const uint8_t strand = s[1] == '+' ? 0 : 1;
-        std::string codes;
+        char codes[16];
+        int n_codes = 0;
         size_t si = 2;
         if (isdigit((unsigned char)s[2])) {
             long c = 0;
-            while (si < s.size() && isdigit((unsigned char)s[si])) c = c * 10 + (s[si++] - '0');
+            while (si < sl && isdigit((unsigned char)s[si])) c = c * 10 + (s[si++] - '0');
             const char code = chebi_to_code(c);
-            if (!code) { err = "Unrecognised ChEBI code in edit series " + s; return false; }
-            codes += code;
+            if (!code) { err = "Unrecognised ChEBI code in edit series " + series(); return false; }
+            codes[n_codes++] = code;
         } else {
-            for (; si < s.size() && s[si] != ',' && s[si] != ';'; ++si)
-                if (s[si] != '.' && s[si] != '?') codes += s[si];
-        }
-        std::vector<int> deltas;
-        while (si < s.size() && s[si] != ';') {
-            if (s[si] != ',') { err = "Illegal character in edit series " + s; return false; }
-            ++si;
-            if (si >= s.size() || !isdigit((unsigned char)s[si])) { err = "Illegal character in edit series " + s; return false; }
-            long d = 0;
-            while (si < s.size() && isdigit((unsigned char)s[si])) d = d * 10 + (s[si++] - '0');
-            deltas.push_back((int)d);
+            for (; si < sl && s[si] != ',' && s[si] != ';'; ++si)
+                if (s[si] != '.' && s[si] != '?') {
+                    if (n_codes == 16) { err = "Too many modification codes in edit series " + series(); return false; }
+                    codes[n_codes++] = s[si];
+                }
         }
         int qoff = 0;
-        for (int d : deltas) {  // bam_mod_parser.cpp:196-229
-            int cnt = 0;
+        while (si < sl && s[si] != ';') {  // bam_mod_parser.cpp:184-229, one delta at a time
+            if (s[si] != ',') { err = "Illegal character in edit series " + series(); return false; }
+            ++si;
+            if (si >= sl || !isdigit((unsigned char)s[si])) { err = "Illegal character in edit series " + series(); return false; }
+            long d = 0;
+            while (si < sl && isdigit((unsigned char)s[si])) d = d * 10 + (s[si++] - '0');
+            long cnt = 0;
             while (cnt < d) {
-                if (qoff >= L) { err = "edit series runs past the read end: " + s; return false; }
-                if (fwd_strand_base(r, qoff) == ub) ++cnt;
+                if (qoff >= L) { err = "edit series runs past the read end: " + series(); return false; }
+                if (fwd[(size_t)qoff] == ub) ++cnt;
                 ++qoff;
             }
-            while (qoff < L && fwd_strand_base(r, qoff) != ub) ++qoff;
-            if (qoff >= L) { err = "edit series runs past the read end: " + s; return false; }
-            for (char code : codes) {
+            while (qoff < L && fwd[(size_t)qoff] != ub) ++qoff;
+            if (qoff >= L) { err = "edit series runs past the read end: " + series(); return false; }
+            for (int c = 0; c < n_codes; ++c) {
                 if (pi >= probs.size()) { err = "ML is shorter than the MM edit lists"; return false; }
-                mods.push_back(BaseMod{qoff, strand, ub, code, probs[pi++]});
+                mods.push_back(BaseMod{qoff, strand, ub, codes[c], probs[pi++]});
             }
             ++qoff;
         }

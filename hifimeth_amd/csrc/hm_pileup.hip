@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -549,10 +550,23 @@ int hm_pileup_submit_read(hm_pileup_t* p, uint32_t order, int32_t flag, int32_t 
     if (sid < 0 || sid >= n_seqs) return pfail(p, HM_EINVAL, "sequence index out of range");
     const int64_t ssize = p->seq_off[sid + 1] - p->seq_off[sid];
     if (pos < 0 || pos > ssize) return pfail(p, HM_EDATA, "alignment position outside the reference sequence");
-    for (int i = 0; i < l_qseq; ++i) {
-        const int c = (i & 1) ? (seq4[i >> 1] & 15) : (seq4[i >> 1] >> 4);
-        if (c != 1 && c != 2 && c != 4 && c != 8 && c != 15)
-            return pfail(p, HM_EDATA, "Illegal BAM base encoded value " + std::to_string(c));
+    {   // s_decode_bam_query_base accepts the nibbles 1, 2, 4, 8, 15 only (bam_info.cpp:100-121); two per byte
+        static const auto ok = [] {
+            std::array<uint8_t, 256> t{};
+            auto good = [](int c) { return c == 1 || c == 2 || c == 4 || c == 8 || c == 15; };
+            for (int b = 0; b < 256; ++b) t[(size_t)b] = good(b >> 4) && good(b & 15);
+            return t;
+        }();
+        const int full = l_qseq >> 1;
+        int bad = -1;
+        for (int i = 0; i < full; ++i)
+            if (!ok[seq4[i]]) { bad = i; break; }
+        if (bad < 0 && (l_qseq & 1) && !ok[(seq4[full] & 0xf0) | 1]) bad = full;
+        if (bad >= 0) {
+            const int hi = seq4[bad] >> 4, lo = seq4[bad] & 15;
+            const bool hi_bad = !(hi == 1 || hi == 2 || hi == 4 || hi == 8 || hi == 15);
+            return pfail(p, HM_EDATA, "Illegal BAM base encoded value " + std::to_string(hi_bad ? hi : lo));
+        }
     }
     // cigar_to_alignment (bam_info.cpp:262-371) without the strings: match runs + column count
     const size_t runs_before = p->runs.size();
