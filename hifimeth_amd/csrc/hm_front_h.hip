@@ -481,13 +481,15 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         __syncthreads();
         if (dbg && dbg_layer == 5 && g == 0) dump_planes<T::L5, 96, T::RS96>(h1, l1, dbg);
 
-        ConvH<NW, 96, 3, 96, T::L6, T::RS96, 4, 2, 3, S, T::C5_SS, 0, !W16>::run(
+        // conv6 / conv7 as 1xN grids (a wave owns one 16-channel tile and every position): with 4x2 / 2x4 grids four
+        // waves fetched the same weight fragments and the vector-memory pipe, not the MFMA, set the pace
+        ConvH<NW, 96, 3, 96, T::L6, T::RS96, 1, 6, 3, S, T::C5_SS, 0, !W16>::run(
             h1, l1, wf(5), EpiPlanesS<T::L6, T::RS96, T::C6_SS>{h0, l0, W.bias[5]});
         zero_pad_rows_h<S, T::L6, 96>(h0, l0, T::RS96, T::C6_SS);
         __syncthreads();
         if (dbg && dbg_layer == 6 && g == 0) dump_planes<T::L6, 96, T::RS96>(h0, l0, dbg);
 
-        ConvH<NW, 96, 3, 64, T::L7, T::RS96, 2, 4, 3, S, T::C6_SS, 0, !W16>::run(
+        ConvH<NW, 96, 3, 64, T::L7, T::RS96, 1, 4, 3, S, T::C6_SS, 0, !W16>::run(
             h0, l0, wf(6), EpiPlanesS<T::L7, T::RS64, T::C7_SS>{h1, l1, W.bias[6]});
         zero_pad_rows_h<S, T::L7, 64>(h1, l1, T::RS64, T::C7_SS);
         __syncthreads();
