@@ -215,3 +215,54 @@ def test_pileup_dist_driver(P, tmp_path, force_collectives):
     want = P.pileup([_as_dict(x) for x in reads], genome)
     for c in ("CpG", "CHG", "CHH"):
         assert open(f"{prefix}.{c}.cov.bed").read() == want["bed"][c]
+
+
+def test_pileup_high_error_alignments(P):
+    """many short match runs (10 % substitutions / insertions / deletions): motifs straddling op boundaries, runs of
+    length 1-2, soft clips on both ends"""
+    for eqx in (True, False):
+        genome, reads = _data(n=40, eqx=eqx, err=0.10, seed=71, median_len=900)
+        want = P.pileup([_as_dict(r) for r in reads], genome)
+        assert len(want["records"]) > 1000
+        pu = _run(genome, reads, batch=9)
+        _check(P, genome, reads, pu, want)
+        pu.close()
+
+
+def test_pileup_shard_invariance_and_linearity():
+    """size-independent properties at a larger size (no oracle): two engines over disjoint halves of the records,
+    planes summed / max-ed as the reduce-scatter does, equal one engine over everything; counters add up to the
+    number of projected calls; thresholds only move calls between pcov and ncov."""
+    import torch
+    from hifimeth_amd.pileup import MethylationPileup
+    genome, reads = _data(n=400, seed=91, median_len=2500, length=60000)
+    n_loci = sum(len(s) for _, s in genome)
+
+    def run(sel, thr, planes=None):
+        pu = MethylationPileup(genome, planes=planes)
+        for i in sel:
+            pu.add(reads[i], order=i)
+        pu.flush()
+        n = pu.num_records()
+        bins = pu.histograms()
+        pu.count(thr)
+        return pu, n, bins
+
+    whole, n_all, bins_all = run(range(len(reads)), [128, 128, 128])
+    loci = whole.loci()
+    assert n_all > 100000 and int(loci["pcov"].sum() + loci["ncov"].sum()) == n_all
+    planes = [[torch.zeros(n_loci, dtype=torch.int32, device="cuda") for _ in range(3)] for _ in range(2)]
+    a, n_a, bins_a = run(range(0, len(reads), 2), [128, 128, 128], planes[0])
+    b, n_b, bins_b = run(range(1, len(reads), 2), [128, 128, 128], planes[1])
+    torch.cuda.synchronize()
+    assert n_a + n_b == n_all and (bins_a + bins_b == bins_all).all()
+    merged = [planes[0][0] + planes[1][0], planes[0][1] + planes[1][1], torch.maximum(planes[0][2], planes[1][2])]
+    got = a.loci(0, n_loci, planes=merged, plane_base=0)
+    assert (got == loci).all()
+    lo, _, _ = run(range(len(reads)), [1, 1, 1])
+    hi, _, _ = run(range(len(reads)), [255, 255, 255])
+    l1, l2 = lo.loci(), hi.loci()
+    assert (l1["gpos"] == l2["gpos"]).all() and (l1["pcov"] + l1["ncov"] == l2["pcov"] + l2["ncov"]).all()
+    assert (l1["pcov"] >= l2["pcov"]).all() and l1["pcov"].sum() > l2["pcov"].sum()
+    for x in (whole, a, b, lo, hi):
+        x.close()
