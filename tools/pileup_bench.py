@@ -49,6 +49,29 @@ def call_like_mods(fwd: np.ndarray, rng) -> np.ndarray:
     return m
 
 
+def cpu_baseline(genome, chrom, starts, staged, read_len, n_sample=600, repeat=12):
+    """The reference's BamQuerySequence::init + BamMapInfo::init + extract_{cpg,chg,chh}_mapped_samples
+    (src/corelib/bam_info.cpp:169-439, 5mc_motif_finder.cpp), built from its sources by oracle/ref_build, one thread."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref", "ref_align")
+    if not os.path.exists(exe):
+        return None
+    n = min(n_sample, len(staged))
+    with tempfile.TemporaryDirectory() as d:
+        fa = os.path.join(d, "g.fa")
+        with open(fa, "w") as f:
+            f.write(">chr1\n" + genome[0][1] + "\n")
+        recs = "".join(f"{staged[i][0]} 0 {int(starts[i])} {read_len}= {chrom[int(starts[i]):int(starts[i]) + read_len].tobytes().decode()}\n"
+                       for i in range(n))
+        r = subprocess.run([exe, "-t", str(repeat), fa], input=recs.encode(), capture_output=True, check=True)
+    t = r.stdout.decode().split()
+    cols, secs = int(t[4]), float(t[-1])
+    return dict(value=round(cols / secs), unit="aligned columns/s", cores=1, kind="reference",
+                sample=f"{n} reads x {repeat} passes = {cols} columns through the reference's alignment projection "
+                       f"(ref_align -t), {secs:.1f} s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--genome-mb", type=float, default=20)
@@ -57,6 +80,8 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="reads per hm_pileup_run")
     ap.add_argument("--repeat", type=int, default=3, help="timed passes over the staged read set")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--cpu-baseline", action="store_true",
+                    help="time the reference's own projection code (oracle/_ref/ref_align -t) on a bounded sample")
     a = ap.parse_args()
 
     rng = np.random.default_rng(1)
@@ -117,6 +142,8 @@ def main():
     if a.check:                                    # every pass (and the warm-up) adds the same records
         total = int((loci["pcov"].astype(np.int64) + loci["ncov"]).sum())
         out["check_total_records"] = total == recs_per_pass * (a.repeat + 1)
+    if a.cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(genome, chrom, starts, staged, a.read_len)
     print(json.dumps(out))
 
 
