@@ -273,7 +273,7 @@ __global__ __launch_bounds__(PREP_THREADS) void emit_kernel(const ReadDesc* __re
 // materialised 401x8 fp32 windows: one thread per window ROW (32 contiguous bytes), rows of consecutive sites
 // back to back, so a wave writes 2 KB contiguous; the 1 KB decode table sits in LDS (12 832 B / site out).
 // (One float4 per lane -- perfectly contiguous wave stores, but twice the index arithmetic -- measured slower:
-//  3.4 vs 4.5 TB/s.)
+//  3.4 vs 4.5 TB/s.  Non-temporal stores halve the rate: 2.3 TB/s.)
 __global__ __launch_bounds__(256) void window_kernel(const Site* __restrict__ sites, int n,
                                                       const ReadDesc* __restrict__ reads,
                                                       const uint8_t* __restrict__ bases,
