@@ -57,6 +57,7 @@ def cpu_baseline(reads, gpu_calls=None, budget_s=15.0):
     sites = 0
     nreads = 0
     worst, nml, ncheck = 0.0, 0, 0
+    deltas = []
     for rid, rd in enumerate(reads):
         if not rd.has_kinetics() or rd.l_qseq < 1000:
             continue
@@ -71,7 +72,9 @@ def cpu_baseline(reads, gpu_calls=None, budget_s=15.0):
             got = gpu_calls[gpu_calls["read_id"] == rid]
             order = np.lexsort((want["qoff"], want["strand"]))
             assert len(got) == len(order) and np.array_equal(got["qoff"], want["qoff"][order]), "site lists differ"
-            worst = max(worst, float(np.abs(got["p"] - want["p"][order]).max(initial=0)))
+            d = np.abs(got["p"] - want["p"][order])
+            deltas.append(d)
+            worst = max(worst, float(d.max(initial=0)))
             nml += int((got["scaled_prob"] != want["ml"][order]).sum())
             ncheck += len(got)
             t0 += time.perf_counter() - tchk  # keep the comparison out of the timed span
@@ -83,7 +86,9 @@ def cpu_baseline(reads, gpu_calls=None, budget_s=15.0):
                      f"oracle/hm_oracle.c fp32, OpenMP over sites, {dt:.1f} s"}
     parity = None
     if gpu_calls is not None:
-        parity = {"sites_checked": ncheck, "max_abs_dp_vs_oracle": worst, "ml_bytes_off_by_1lsb": nml, "tolerance": 1e-4}
+        alld = np.concatenate(deltas) if deltas else np.zeros(1)
+        parity = {"sites_checked": ncheck, "max_abs_dp_vs_oracle": worst, "mean_abs_dp": float(alld.mean()),
+                  "p999_abs_dp": float(np.quantile(alld, 0.999)), "ml_bytes_off_by_1lsb": nml, "tolerance": 1e-4}
     return out, parity
 
 
@@ -230,6 +235,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(reads, gpu_calls)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            # external sanity bound, DERIVED not measured: the reference README's "~2 hours on 48
+            # CPU threads" for 30x Arabidopsis, ~1.1e9 sites => ~1.5e5 sites/s; the north-star asks for >= 30x of it
+            out["readme_derived_48_thread_baseline"] = {"value": 1.5e5, "unit": "sites/s", "label": "derived, not measured",
+                                                        "ratio": out["value"] / 1.5e5}
         print(json.dumps(out))
     mc.close()
     if dist is not None:
