@@ -83,7 +83,7 @@ def cpu_baseline(reads, gpu_calls=None, budget_s=15.0):
     dt = time.perf_counter() - t0
     out = {"value": sites / dt, "unit": "sites/s", "cores": cores, "kind": "port",
            "sample": f"first {nreads} reads of the rank-0 batch ({sites} sites, all contexts), "
-                     f"oracle/hm_oracle.c fp32, OpenMP over sites, {dt:.1f} s"}
+                     f"oracle/hm_oracle.c fp32 ({O.variant} build), OpenMP over sites, {dt:.1f} s"}
     parity = None
     if gpu_calls is not None:
         alld = np.concatenate(deltas) if deltas else np.zeros(1)
