@@ -46,9 +46,9 @@ struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     // grow to at least `bytes`, keeping the first `keep` bytes
-    void reserve(size_t bytes, size_t keep = 0, hipStream_t st = nullptr) {
+    void reserve(size_t bytes, size_t keep = 0, hipStream_t st = nullptr, bool exact = false) {
         if (bytes <= cap) return;
-        const size_t want = bytes + bytes / 2 + 256;
+        const size_t want = exact ? bytes : bytes + bytes / 2 + 256;  // exact: genome-sized buffers, allocated once
         void* q = nullptr;
         HIP_TRY(hipMalloc(&q, want));
         if (keep) {
@@ -506,13 +506,13 @@ int hm_pileup_set_reference(hm_pileup_t* p, int32_t n_seqs, const int64_t* seq_l
     if (total >= (int64_t(1) << 40)) return pfail(p, HM_EINVAL, "reference longer than 2^40 bases");
     try {
         HIP_TRY(hipSetDevice(p->device));
-        p->d_ref.reserve((size_t)total + 4);
+        p->d_ref.reserve((size_t)total + 4, 0, nullptr, true);
         HIP_TRY(hipMemcpyAsync(p->d_ref.p, bases, (size_t)total, hipMemcpyHostToDevice, p->stream));
         if (p->own_planes) {
             const size_t bytes = (size_t)std::max<int64_t>(total, 1) * 4;
-            p->d_pcov.reserve(bytes);
-            p->d_ncov.reserve(bytes);
-            p->d_key.reserve(bytes);
+            p->d_pcov.reserve(bytes, 0, nullptr, true);
+            p->d_ncov.reserve(bytes, 0, nullptr, true);
+            p->d_key.reserve(bytes, 0, nullptr, true);
             p->pcov = p->d_pcov.as<int32_t>();
             p->ncov = p->d_ncov.as<int32_t>();
             p->key = p->d_key.as<uint32_t>();
