@@ -436,6 +436,8 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
     half_t* h1 = smem + 2 * T::P0;
     half_t* l1 = smem + 2 * T::P0 + T::P1;
     float* hfc = reinterpret_cast<float*>(h1);  // fc1 activations (fp32) reuse buffer 1
+    __shared__ float fc2w[2 * 256 + 2];          // fc2 weights + bias stay in LDS for the whole kernel
+    for (int i = threadIdx.x; i < 2 * 256 + 2; i += NW * 64) fc2w[i] = i < 512 ? W.fc2_w[i] : W.fc2_b[i - 512];
     auto wf = [&](int i) { return reinterpret_cast<const half_t*>(W.wfrag_h[i]); };
 
     // act4 of a group of S sites = S * 600 float4; thread t owns elements t + 512 k.  The next group's elements are
@@ -508,14 +510,14 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         if (threadIdx.x < S * 16) {
             const int site = threadIdx.x >> 4, o = (threadIdx.x >> 3) & 1, part = threadIdx.x & 7;
             const float* h = hfc + site * T::HRS + part * 32;
-            const float* w2 = W.fc2_w + o * 256 + part * 32;
+            const float* w2 = fc2w + o * 256 + part * 32;
             float sum = 0.f;
 #pragma unroll 8
             for (int k = 0; k < 32; ++k) sum = fmaf(h[k], w2[k], sum);
             sum += __shfl_xor(sum, 4, 64);
             sum += __shfl_xor(sum, 2, 64);
             sum += __shfl_xor(sum, 1, 64);
-            sum += W.fc2_b[o];
+            sum += fc2w[512 + o];
             const float other = __shfl_xor(sum, 8, 64);
             if ((threadIdx.x & 15) == 0 && site < nv) {
                 const float v0 = sum, v1 = other;
