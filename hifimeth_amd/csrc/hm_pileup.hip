@@ -200,7 +200,7 @@ __device__ __forceinline__ void stage_record(bool pred, const PRec& rec, PRec* _
 // ---- projection (pileup.cpp:286-347, 5mc_motif_finder.cpp:104-144) -----------------------------------------
 // A workgroup walks PTILE consecutive columns, stages its records in LDS and appends them to the global list with
 // ONE atomic (same-address atomics from every wavefront serialise in L2 and dominated an earlier version).
-constexpr int PTILE = 2048;
+constexpr int PTILE = 1024;
 
 __global__ __launch_bounds__(TPB) void project_kernel(const PRun* __restrict__ runs, const int64_t* __restrict__ col0,
                                                        int n_runs, int64_t n_cols, const PRead* __restrict__ reads,
@@ -662,8 +662,8 @@ int hm_pileup_run(hm_pileup_t* p) {
         HIP_TRY(hipMemsetAsync(p->d_plane.p, 0, 4 * (size_t)std::max<int64_t>(p->plane_len, 1), st));
         HIP_TRY(hipMemsetAsync(p->d_matches.p, 0, 4 * (size_t)n_reads, st));
 
-        if (n_mods)
-            hipLaunchKernelGGL(mods_kernel, dim3(grid_for(n_mods, 4096)), dim3(TPB), 0, st, p->d_mods.as<PMod>(), n_mods,
+        if (n_mods)  // <= 1024 workgroups: each flushes up to 768 histogram bins with same-address global atomics (~10 ns each)
+            hipLaunchKernelGGL(mods_kernel, dim3(grid_for(n_mods, 1024)), dim3(TPB), 0, st, p->d_mods.as<PMod>(), n_mods,
                                p->d_reads.as<PRead>(), p->d_slab.as<uint8_t>(), p->d_plane.as<uint32_t>(),
                                p->d_bins.as<unsigned long long>());
         if (cols > 0) {
