@@ -9,6 +9,7 @@ from hifimeth_amd.synth import synth_reads
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 threads = sys.argv[2] if len(sys.argv) > 2 else "16"
+contexts = sys.argv[3] if len(sys.argv) > 3 else "cpg,chg,chh"
 tmp = os.environ.get("TMPDIR", "/tmp")
 src, dst = os.path.join(tmp, "e2e_in.bam"), os.path.join(tmp, "e2e_out.bam")
 t = time.time(); reads = synth_reads(n, seed=20250220); bamutil.reads_to_bam(src, reads, level=1)
@@ -16,7 +17,7 @@ print(f"synthetic BAM: {n} reads, {sum(r.l_qseq for r in reads)/1e6:.1f} Mbases,
 cli = os.path.join(ROOT, "hifimeth_amd", "bin", "hifimeth-hip")
 for b in ("250", "1000"):
     t = time.time()
-    p = subprocess.run([cli, "call", "-b", b, "-t", threads, src, dst], stderr=subprocess.PIPE, text=True)
+    p = subprocess.run([cli, "call", "-c", contexts, "-b", b, "-t", threads, src, dst], stderr=subprocess.PIPE, text=True)
     dt = time.time() - t
     tail = [l for l in p.stderr.splitlines() if "##" in l]
     print(f"-b {b}: exit {p.returncode}, {dt:.2f} s wall;", " | ".join(x.strip() for x in tail), flush=True)
