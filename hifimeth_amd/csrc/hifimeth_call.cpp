@@ -217,34 +217,54 @@ int cmd_call(int argc, char** argv) {
         sl.active = false;
     };
 
-    size_t b = 0;
-    bool eof = false;
-    while (!eof && !failed) {
-        Slot& sl = slots[b % slots.size()];
-        if (sl.active) finish(sl);
-        if (failed) break;
-        sl.recs.clear();
-        while ((int)sl.recs.size() < o.read_batch) {
+    // A producer thread inflates and parses batch k+1 while this thread stages batch k, collects an older batch from
+    // its engine, builds its tags and deflates it (the reader is touched by the producer only, the writer by this thread).
+    struct Batch {
+        std::vector<BamRecord> recs;
+        bool eof = false;
+        std::string err;
+    };
+    Batch nb[2];
+    auto produce = [&](Batch& bt) {
+        bt.recs.clear();
+        bt.err.clear();
+        while ((int)bt.recs.size() < o.read_batch) {
             BamRecord r;
-            if (!read_record(in, r, err)) {
-                if (!err.empty()) { fprintf(stderr, "[%s] %s: %s\n", kName, o.in.c_str(), err.c_str()); failed = true; }
-                eof = true;
-                break;
+            if (!read_record(in, r, bt.err)) { bt.eof = true; break; }
+            bt.recs.push_back(std::move(r));
+        }
+    };
+    size_t b = 0;
+    int cur = 0;
+    produce(nb[0]);
+    while (!failed) {
+        Batch& bt = nb[cur];
+        if (!bt.err.empty()) { fprintf(stderr, "[%s] %s: %s\n", kName, o.in.c_str(), bt.err.c_str()); failed = true; break; }
+        std::thread producer;
+        if (!bt.eof) producer = std::thread(produce, std::ref(nb[cur ^ 1]));
+        if (!bt.recs.empty()) {
+            Slot& sl = slots[b % slots.size()];
+            if (sl.active) finish(sl);
+            if (!failed) {
+                sl.recs = std::move(bt.recs);
+                bt.recs.clear();
+                for (size_t i = 0; i < sl.recs.size(); ++i) {
+                    const BamRecord& r = sl.recs[i];
+                    const KineticsView kv = kinetics_of(r);
+                    const int rc = hm_submit_read(sl.eng, (int32_t)i, r.l_qseq(), r.flag(), r.seq4(), kv.arr[0], kv.width[0],
+                                                  kv.arr[1], kv.width[1], kv.arr[2], kv.width[2], kv.arr[3], kv.width[3]);
+                    if (rc < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(sl.eng)); failed = true; break; }
+                }
+                if (!failed && hm_flush(sl.eng) < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(sl.eng)); failed = true; }
+                if (!failed) {
+                    sl.active = true;
+                    ++b;
+                }
             }
-            sl.recs.push_back(std::move(r));
         }
-        if (sl.recs.empty() || failed) break;
-        for (size_t i = 0; i < sl.recs.size(); ++i) {
-            const BamRecord& r = sl.recs[i];
-            const KineticsView kv = kinetics_of(r);
-            const int rc = hm_submit_read(sl.eng, (int32_t)i, r.l_qseq(), r.flag(), r.seq4(), kv.arr[0], kv.width[0],
-                                          kv.arr[1], kv.width[1], kv.arr[2], kv.width[2], kv.arr[3], kv.width[3]);
-            if (rc < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(sl.eng)); failed = true; break; }
-        }
-        if (failed) break;
-        if (hm_flush(sl.eng) < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(sl.eng)); failed = true; break; }
-        sl.active = true;
-        ++b;
+        if (producer.joinable()) producer.join();
+        if (bt.eof) break;
+        cur ^= 1;
     }
     for (size_t k = 0; k < slots.size() && !failed; ++k) {
         Slot& sl = slots[(b + k) % slots.size()];
