@@ -16,6 +16,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -165,8 +169,8 @@ int cmd_call(int argc, char** argv) {
     add_pg(hdr, argc, argv);
     write_header(out, hdr);
 
-    // two engines per device: while the GPU works on one batch the host decodes / stages the next one
-    std::vector<Slot> slots(o.devices.size() * 2);
+    // three engines per device: one batch being staged, one on the GPU, one being tagged / written
+    std::vector<Slot> slots(o.devices.size() * 3);
     for (size_t s = 0; s < slots.size(); ++s) {
         const int dev = o.devices[s % o.devices.size()];
         if (hm_create(&slots[s].eng, o.model_dir.c_str(), o.ctx_mask, dev) < 0) {
@@ -178,7 +182,7 @@ int cmd_call(int argc, char** argv) {
     }
     size_t all_reads = 0, all_bases = 0, all_ctx[3] = {0, 0, 0};
     std::vector<hm_call_t> calls;
-    bool failed = false;
+    std::atomic<bool> failed{false};
 
     auto finish = [&](Slot& sl) {
         hm_engine_t* e = sl.eng;
@@ -214,7 +218,6 @@ int cmd_call(int argc, char** argv) {
         all_reads += sl.recs.size();
         fprintf(stderr, "[%s] %zu reads done\n", kName, all_reads);
         sl.recs.clear();
-        sl.active = false;
     };
 
     // A producer thread inflates and parses batch k+1 while this thread stages batch k, collects an older batch from
@@ -234,6 +237,29 @@ int cmd_call(int argc, char** argv) {
             bt.recs.push_back(std::move(r));
         }
     };
+    // consumer thread: collects finished batches in submission order (hm_sync + hm_drain), builds the tags, deflates
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<size_t> ready;
+    bool no_more = false;
+    std::thread writer([&]() {
+        for (;;) {
+            size_t idx;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !ready.empty() || no_more; });
+                if (ready.empty()) return;
+                idx = ready.front();
+                ready.pop_front();
+            }
+            if (!failed) finish(slots[idx]);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                slots[idx].active = false;
+            }
+            cv.notify_all();
+        }
+    });
     size_t b = 0;
     int cur = 0;
     produce(nb[0]);
@@ -244,7 +270,10 @@ int cmd_call(int argc, char** argv) {
         if (!bt.eof) producer = std::thread(produce, std::ref(nb[cur ^ 1]));
         if (!bt.recs.empty()) {
             Slot& sl = slots[b % slots.size()];
-            if (sl.active) finish(sl);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !sl.active; });  // the consumer is done with this engine's previous batch
+            }
             if (!failed) {
                 sl.recs = std::move(bt.recs);
                 bt.recs.clear();
@@ -257,7 +286,12 @@ int cmd_call(int argc, char** argv) {
                 }
                 if (!failed && hm_flush(sl.eng) < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(sl.eng)); failed = true; }
                 if (!failed) {
-                    sl.active = true;
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        sl.active = true;
+                        ready.push_back(b % slots.size());
+                    }
+                    cv.notify_all();
                     ++b;
                 }
             }
@@ -266,10 +300,12 @@ int cmd_call(int argc, char** argv) {
         if (bt.eof) break;
         cur ^= 1;
     }
-    for (size_t k = 0; k < slots.size() && !failed; ++k) {
-        Slot& sl = slots[(b + k) % slots.size()];
-        if (sl.active) finish(sl);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        no_more = true;
     }
+    cv.notify_all();
+    writer.join();
     for (auto& sl : slots) hm_destroy(sl.eng);
     if (failed) return EXIT_FAILURE;
     if (!out.close()) { fprintf(stderr, "[%s] %s: %s\n", kName, o.out.c_str(), out.error().c_str()); return EXIT_FAILURE; }
