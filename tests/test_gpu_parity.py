@@ -397,3 +397,29 @@ def test_full_size_properties(mc):
     a = mc.call(reads[:half], first_id=0)
     b = mc.call(reads[half:], first_id=half)
     assert np.concatenate([a, b]).tobytes() == calls.tobytes()
+
+
+def test_extreme_kinetics_and_homopolymers(mc, oracle, oracle_models):
+    """saturated (255 = 952 frames), zero and alternating kinetics codes, u16 frame arrays at and above the 952 cap,
+    on poly-C / CG-repeat / random sequence: the largest activations the network can see must stay finite in the
+    split-half planes and within tolerance of the fp32 oracle."""
+    from hifimeth_amd.synth import read_from_ascii
+    rng = np.random.default_rng(5)
+    L = 1400
+    seqs = [b"C" * L, b"CG" * (L // 2), bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), L).tobytes()),
+            b"CCA" * (L // 3) + b"CC"]
+    reads = []
+    for i, sq in enumerate(seqs):
+        for j, fill in enumerate((255, 0, None)):
+            if fill is None:
+                k = [np.where(np.arange(len(sq)) % 2 == 0, 255, 0).astype(np.uint8) for _ in range(4)]
+            else:
+                k = [np.full(len(sq), fill, np.uint8) for _ in range(4)]
+            reads.append(read_from_ascii(sq, *k, flag=4 if (i + j) % 2 else 20, name=f"x{i}_{j}"))
+        wide = [np.full(len(sq), v, np.uint16) for v in (952, 2000, 65535, 447)]
+        reads.append(read_from_ascii(sq, *wide, flag=4, name=f"w{i}"))
+    calls = mc.call(reads)
+    assert np.isfinite(calls["p"]).all()
+    n, nml, worst = _check_calls(calls, reads, oracle, oracle_models, 7)
+    assert n > 5000
+    print(f"extreme kinetics: {n} sites, max|dp|={worst:.2e}")
