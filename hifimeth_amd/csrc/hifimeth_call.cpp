@@ -7,6 +7,7 @@
 //     hifimeth-hip bamcopy IN.bam OUT.bam             (BGZF/BAM round trip)
 //     hifimeth-hip tagtest IN.bam CALLS.bin OUT.bam   (apply hm_call_t records, read_id = record index)
 //     hifimeth-hip pileup [OPTIONS] REF.fa MOD.bam PREFIX   (hifimeth_pileup.cpp)
+//     hifimeth-hip corr [-c N] A.cov.bed B.cov.bed          (Pearson r of two pileup outputs, hifimeth_pileup.cpp)
 //     hifimeth-hip modstats IN.bam                    (MM/ML parser + per-context histograms + adaptive thresholds)
 #include <unistd.h>
 
@@ -410,6 +411,7 @@ int cmd_modstats(int argc, char** argv) {
 
 int cmd_pileup(int argc, char** argv);   // hifimeth_pileup.cpp
 int cmd_fastats(int argc, char** argv);  // hifimeth_pileup.cpp
+int cmd_corr(int argc, char** argv);     // hifimeth_pileup.cpp
 
 int main(int argc, char** argv) {
     if (argc < 2) { usage(); return EXIT_FAILURE; }
@@ -420,6 +422,7 @@ int main(int argc, char** argv) {
     if (cmd == "modstats") return cmd_modstats(argc, argv);
     if (cmd == "pileup") return cmd_pileup(argc, argv);
     if (cmd == "fastats") return cmd_fastats(argc, argv);
+    if (cmd == "corr") return cmd_corr(argc, argv);
     usage();
     return EXIT_FAILURE;
 }

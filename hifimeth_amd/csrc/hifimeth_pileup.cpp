@@ -5,8 +5,11 @@
 // The host parses the BAM and the MM/ML lists (parallel over the reads of a batch); alignment projection,
 // histograms and per-locus counting run on the GPU through the hm_pileup_* C ABI.  No temporary file is written:
 // the projected calls stay in HBM until the thresholds are known.
+#include <zlib.h>
+
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -75,6 +78,82 @@ bool mapped_and_sorted(const BamHeader& h) {
 }
 
 }  // namespace
+
+// corr [-c min_cov] bed1 bed2 : Pearson correlation of the methylation frequencies of the loci two *.cov.bed files
+// share (src/app/hifimeth/pileup_correlation.cpp:101-210): rows with pcov + ncov < min_cov (default 5) are dropped,
+// loci are keyed by (chromosome id in order of first appearance over both files, start); host only, no GPU.
+int cmd_corr(int argc, char** argv) {
+    int min_cov = 5;
+    int i = 2;
+    for (; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a.size() < 2 || a[0] != '-') break;
+        if (a == "-c" && i + 1 < argc) min_cov = atoi(argv[++i]);
+        else { fprintf(stderr, "ERROR: unrecognised option %s", a.c_str()); return 1; }
+    }
+    if (argc - i != 2) {
+        fprintf(stderr, "USAGE:\n  %s corr [-c <min coverage, default 5>] bed1 bed2\n", argv[0]);
+        return 1;
+    }
+    fprintf(stderr, "\n\n====================> Parameters:\nmin-cov: %d\nbed1: %s\nbed2: %s\n\n\n", min_cov, argv[i], argv[i + 1]);
+    std::vector<std::string> chr_names;
+    auto chr_id = [&](const std::string& nm) {
+        for (size_t k = 0; k < chr_names.size(); ++k)
+            if (chr_names[k] == nm) return (uint64_t)k;
+        chr_names.push_back(nm);
+        return (uint64_t)chr_names.size() - 1;
+    };
+    auto load = [&](const char* path, std::vector<std::pair<uint64_t, double>>& out) {
+        gzFile f = gzopen(path, "rb");
+        if (!f) { fprintf(stderr, "ERROR: cannot open %s\n", path); return false; }
+        static char line[1 << 16];
+        std::string last;
+        uint64_t sid = 0;
+        while (gzgets(f, line, sizeof line)) {
+            char* col[6];
+            int nc = 0;
+            char* p = line;
+            col[nc++] = p;
+            for (; *p && nc < 6; ++p)
+                if (*p == '\t') { *p = 0; col[nc++] = p + 1; }
+            if (nc < 6) continue;
+            const int pcov = atoi(col[4]), ncov = atoi(col[5]);
+            if (pcov + ncov < min_cov) continue;
+            if (last != col[0]) { last = col[0]; sid = chr_id(last); }
+            out.emplace_back((sid << 32) | (uint64_t)(uint32_t)atoi(col[1]), 1.0 * pcov / (pcov + ncov));
+        }
+        gzclose(f);
+        return true;
+    };
+    std::vector<std::pair<uint64_t, double>> m1, m2;
+    if (!load(argv[i], m1) || !load(argv[i + 1], m2)) return 1;
+    auto by_key = [](const std::pair<uint64_t, double>& x, const std::pair<uint64_t, double>& y) { return x.first < y.first; };
+    std::sort(m1.begin(), m1.end(), by_key);
+    std::sort(m2.begin(), m2.end(), by_key);
+    std::vector<double> x, y;
+    for (size_t a = 0, b = 0; a < m1.size() && b < m2.size();) {
+        if (m1[a].first < m2[b].first) ++a;
+        else if (m1[a].first > m2[b].first) ++b;
+        else { x.push_back(m1[a++].second); y.push_back(m2[b++].second); }
+    }
+    const size_t n = x.size();
+    if (n < 5) { fprintf(stderr, "Intersect genomic loci is less than 5. Skip computation\n"); return 0; }
+    double mx = 0, my = 0;
+    for (size_t k = 0; k < n; ++k) { mx += x[k]; my += y[k]; }
+    mx /= (double)n;
+    my /= (double)n;
+    double cov = 0, vx = 0, vy = 0;
+    for (size_t k = 0; k < n; ++k) {
+        const double dx = x[k] - mx, dy = y[k] - my;
+        cov += dx * dy;
+        vx += dx * dx;
+        vy += dy * dy;
+    }
+    const double corr = (vx == 0 || vy == 0) ? 0.0 : cov / std::sqrt(vx * vy);
+    fprintf(stdout, "Intersect loci: %zu\n", n);
+    fprintf(stderr, "correlation: %g\n", corr);
+    return 0;
+}
 
 // fastats REF.fa : names, lengths and a checksum of the loaded reference as one JSON object (loader tests; no GPU)
 int cmd_fastats(int argc, char** argv) {
