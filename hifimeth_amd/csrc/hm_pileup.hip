@@ -616,9 +616,16 @@ int hm_pileup_submit_read(hm_pileup_t* p, uint32_t order, int32_t flag, int32_t 
     r.primary = (flag & 0x900) ? 0 : 1;
     r.pass = mapq >= p->min_mapq ? 1 : 0;
     const int32_t ri = (int32_t)p->reads.size();
+    const size_t mods_before = p->mods.size();
+    const int64_t m_before = p->n_m_mods;
     for (int64_t i = 0; i < n_mods; ++i) {
         const hm_mod_t& m = mods[i];
-        if (m.qoff < 0 || m.qoff >= l_qseq) { p->runs.resize(runs_before); return pfail(p, HM_EDATA, "modification offset outside the read"); }
+        if (m.qoff < 0 || m.qoff >= l_qseq) {  // leave the staged batch as it was
+            p->runs.resize(runs_before);
+            p->mods.resize(mods_before);
+            p->n_m_mods = m_before;
+            return pfail(p, HM_EDATA, "modification offset outside the read");
+        }
         const bool is_m = m.code == 'm';
         const bool cg = m.unmod_base == 'C' || m.unmod_base == 'G';
         if (!is_m && !cg) continue;
