@@ -646,7 +646,12 @@ bool load_fasta(const std::string& path, Fasta& fa, std::string& err) {
             fa.length.push_back(0);
             in_seq = true;
         } else if (in_seq) {
-            for (size_t i = a; i < b; ++i) fa.bases.push_back((char)toupper((unsigned char)line[i]));
+            const size_t at = fa.bases.size();
+            fa.bases.resize(at + (b - a));
+            for (size_t i = a; i < b; ++i) {
+                const char ch = line[i];
+                fa.bases[at + (i - a)] = (ch >= 'a' && ch <= 'z') ? (char)(ch - 32) : ch;
+            }
             fa.length.back() += (int64_t)(b - a);
         }
     };
