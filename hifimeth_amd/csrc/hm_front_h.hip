@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         mk(1);
 
         // conv1: window (planes B) -> planes A
-        ConvH<NW, 8, G::KT1, 128, G::L1, G::WRS, 2, 4, 2>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[0]),
+        ConvH<NW, 8, G::KT1, 128, G::L1, G::WRS, 2, 4, 3>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[0]),
                                                              EpiPlanes<G::RS>{a_hi, a_lo, W.bias[0]}, [&](int k) __attribute__((always_inline)) { mk(2 + k); });
         mk(4);
         zero_rows_h<128>(a_hi, a_lo, 0, G::L1 + 1, G::RS);
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         if (dbg && dbg_layer == 3 && s == 0) dump_planes<G::L3, 128, G::RS>(a_hi, a_lo, dbg);
 
         // conv4: planes A -> act4[s] (fp32, hand-off to the tail kernel) on 6 waves (one 16-channel tile column
-        // each, weights 5 k-blocks ahead); the other 2 build the next site's window in planes B meanwhile
-        ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 6, 1, 0, 0, !W16>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]),
+        // each, weights 3 k-blocks ahead); the other 2 build the next site's window in planes B meanwhile
+        ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 4, 1, 0, 0, !W16>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]),
                                                             EpiGlobalF<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]}, [&](int k) __attribute__((always_inline)) { mk(14 + k); });
         mk(16);
         const int sn = s + gridDim.x;
