@@ -266,3 +266,28 @@ def test_pileup_shard_invariance_and_linearity():
     assert (l1["pcov"] >= l2["pcov"]).all() and l1["pcov"].sum() > l2["pcov"].sum()
     for x in (whole, a, b, lo, hi):
         x.close()
+
+
+def test_cli_pileup_fasta_order_differs_from_bam_header(P, tmp_path):
+    """records carry BAM tids; the reference resolves them by NAME in the FASTA (HbnDatabase::seq_name2id) and writes the
+    chromosomes in FASTA order (pileup.cpp:514-595) -- here the FASTA lists them in the opposite order, gzipped"""
+    import gzip
+    from bamutil import aligned_to_bam
+    genome, reads = _data(n=60, seed=61)
+    bam, fa, prefix = str(tmp_path / "mod.bam"), str(tmp_path / "ref.fa.gz"), str(tmp_path / "out")
+    aligned_to_bam(bam, genome, reads)
+    with gzip.open(fa, "wt") as f:
+        for n, s in reversed(genome):
+            f.write(f">{n}\n{s}\n")
+    r = subprocess.run([CLI, "pileup", fa, bam, prefix], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = P.pileup([_as_dict(x) for x in reads], genome)
+    for c in ("CpG", "CHG", "CHH"):
+        rows = want["bed"][c].splitlines(keepends=True)
+        by_chr = {n: [l for l in rows if l.split("\t")[0] == n] for n, _ in genome}
+        assert open(f"{prefix}.{c}.cov.bed").read() == "".join("".join(by_chr[n]) for n, _ in reversed(genome))
+    # a reference without one of the chromosomes is an error, as in the reference
+    with gzip.open(fa, "wt") as f:
+        f.write(f">{genome[0][0]}\n{genome[0][1]}\n")
+    r = subprocess.run([CLI, "pileup", fa, bam, prefix + "x"], capture_output=True, text=True)
+    assert r.returncode != 0 and "does not exist" in r.stderr
