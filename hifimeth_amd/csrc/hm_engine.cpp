@@ -206,6 +206,9 @@ void upload_model(hm_engine* e, int ctx, const HostModel& hmw) {
     dm.w.bn = reinterpret_cast<const BnTables*>(base + pk.bn_off);
     for (int i = 0; i < 9; ++i) dm.w.wfrag_h[i] = reinterpret_cast<const uint16_t*>(base + pk.wfrag_h_off[i]);
     dm.w.bn_h = reinterpret_cast<const BnTablesH*>(base + pk.bn_h_off);
+    dm.w.c1f = reinterpret_cast<const uint16_t*>(base + pk.c1f_off);
+    dm.w.c1f_bias = base + pk.c1f_bias_off;
+    dm.w.c1f_corr = base + pk.c1f_corr_off;
     dm.w.k1 = hmw.k1;
     dm.k1 = hmw.k1;
     dm.loaded = true;

@@ -216,6 +216,127 @@ struct EpiGlobalF {
     }
 };
 
+// conv1 of the 13-tap (CHH) model on the staged-read path, with bn0's one-hot half folded into the weights
+// (hm_weights.cpp, "c1f"): the window is kept as three 8-byte-row arrays -- the one-hot channels as EXACT fp16 0/1
+// (no lo plane), the four kinetics channels as hi and lo planes -- and K is walked as 4 blocks of 8 taps x 4
+// channels: two one-hot blocks with 2 products each (w_hi*x, w_lo*x), two kinetics blocks with the usual 3.
+// 10 MFMAs per tile instead of 12.  Same 2x4 wave grid, accumulator layout and epilogue as ConvH.
+template <int NW, int LOUT>
+struct Conv1F {
+    static constexpr int WM = 2, WN = 4, COUT = 128, M = LOUT;
+    static constexpr int MT = (M + 15) / 16, MTW = (MT + WM - 1) / WM, NTW = COUT / 16 / WN;
+
+    template <class Epi, class Mark>
+    static __device__ __forceinline__ void run(const half_t* __restrict__ oh, const half_t* __restrict__ kh,
+                                               const half_t* __restrict__ kl, const half_t* __restrict__ wfrag, Epi epi,
+                                               Mark mark) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm = wave / WN, wn = wave % WN;
+        const int li = lane & 15, lk = lane >> 4;
+        int aoff[MTW];  // halves: row 2m + 2lk of the 4-half rows (taps 2lk, 2lk+1 of a block are one 16-byte read)
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            int m = (wm * MTW + i) * 16 + li;
+            m = m < M ? m : M - 1;
+            aoff[i] = (2 * m + 2 * lk) * 4;
+        }
+        const int nt0 = wn * NTW;
+        f32x4 acc[MTW][NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const float4 bz = *reinterpret_cast<const float4*>(epi.bias + (nt0 + j) * 16 + 4 * lk);
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) acc[i][j] = f32x4{bz.x, bz.y, bz.z, bz.w};
+        }
+        // weights [n-tile][block][plane][lane] half8
+        const half8* wp = reinterpret_cast<const half8*>(wfrag) + (size_t)nt0 * 4 * 128 + lane;
+        half8 w[2][NTW][2];
+        half8 x[2][MTW][2];
+        auto load = [&](auto blk_tag, auto buf_tag) __attribute__((always_inline)) {
+            constexpr int B = decltype(blk_tag)::value, R = decltype(buf_tag)::value;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                w[R][j][0] = wp[(size_t)(j * 4 + B) * 128];
+                w[R][j][1] = wp[(size_t)(j * 4 + B) * 128 + 64];
+            }
+            constexpr int ro = (B & 1) * 8 * 4;  // second block of a half starts 8 rows further down
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                if (B < 2) {
+                    x[R][i][0] = *reinterpret_cast<const half8*>(oh + ro + aoff[i]);
+                } else {
+                    x[R][i][0] = *reinterpret_cast<const half8*>(kh + ro + aoff[i]);
+                    x[R][i][1] = *reinterpret_cast<const half8*>(kl + ro + aoff[i]);
+                }
+            }
+        };
+        auto mma = [&](auto blk_tag, auto buf_tag) __attribute__((always_inline)) {
+            constexpr int B = decltype(blk_tag)::value, R = decltype(buf_tag)::value;
+            // one-hot blocks: (w_hi, x), (w_lo, x); kinetics blocks: (w_hi, x_hi), (w_hi, x_lo), (w_lo, x_hi)
+#pragma unroll
+            for (int pr = 0; pr < (B < 2 ? 2 : 3); ++pr)
+#pragma unroll
+                for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        const int wpl = B < 2 ? pr : (pr == 2 ? 1 : 0), xpl = B < 2 ? 0 : (pr == 1 ? 1 : 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[R][j][wpl], x[R][i][xpl], acc[i][j], 0, 0, 0);
+                    }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        load(I0{}, I0{});
+        mark(0);
+        load(I1{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma(I0{}, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        load(I2{}, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma(I1{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        load(I3{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma(I2{}, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma(I3{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        mark(1);
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            const int m = (wm * MTW + i) * 16 + li;
+            if (m < M) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) epi(m, (nt0 + j) * 16 + 4 * lk, acc[i][j]);
+            }
+        }
+    }
+};
+
+// EpiPlanes for the folded conv1: the first and last output rows reach the conv's zero padding, where the folded
+// constant must not count (see hm_weights.cpp)
+template <int ORS, int LOUT>
+struct EpiPlanesC1 {
+    half_t* hi;
+    half_t* lo;
+    const float* __restrict__ bias;
+    const float* __restrict__ corr;  // [2][128]
+    __device__ __forceinline__ void operator()(int m, int col, f32x4 acc) const {
+        if (m == 0 || m == LOUT - 1) {
+            const float4 c = *reinterpret_cast<const float4*>(corr + (m ? 128 : 0) + col);
+            acc[0] -= c.x; acc[1] -= c.y; acc[2] -= c.z; acc[3] -= c.w;
+        }
+        half4 h, l;
+        split4(acc, h, l);
+        *reinterpret_cast<half4*>(hi + (m + 1) * ORS + col) = h;
+        *reinterpret_cast<half4*>(lo + (m + 1) * ORS + col) = l;
+    }
+};
+
 template <int K1>
 struct GeoH {
     static constexpr int L1 = (KMER + 2 - K1) / 2 + 1;
@@ -346,7 +467,56 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         }
     };
 
-    if ((int)blockIdx.x < n_sites) build_window(blockIdx.x, threadIdx.x, NW * 64);
+    // folded layout (FOLD): three arrays of 4-half rows in region B -- one-hot as exact 0/1, kinetics hi, kinetics lo
+    constexpr bool FOLD = RAW && K1 == 13;
+    half_t* w_oh = b_hi;
+    half_t* w_kh = b_hi + G::WROWS * 4;
+    half_t* w_kl = b_hi + G::WROWS * 8;
+    auto build_window_f = [&](const int s, const int t, const int nt) __attribute__((always_inline)) {
+        const Site st = sites[s];
+        const int L = reads[st.read_idx].len;
+        const int64_t bo = reads[st.read_idx].base_off;
+        const int qoff = st.qoff;
+        const int rev = bases[bo + qoff] == 2;
+        for (int pr = t; pr < G::WROWS; pr += nt) {
+            const int w = pr - 1;
+            uint2 o = make_uint2(0u, 0u), kh2 = o, kl2 = o;
+            if (w >= 0 && w < KMER) {
+                const int j = rev ? qoff + HK - w : qoff - HK + w;
+                uint32_t v[4];
+                if (j < 0 || j >= L) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = bh->zero[4 + c];
+                } else {
+                    int b = bases[bo + j];
+                    uint32_t k = kin[bo + j];
+                    if (rev) {
+                        if (b < 4) b = 3 - b;
+                        k = (k >> 16) | (k << 16);
+                    }
+                    // fp16 1.0 = 0x3c00 in the channel of the base
+                    o.x = b == 0 ? 0x3c00u : b == 1 ? 0x3c000000u : 0u;
+                    o.y = b == 2 ? 0x3c00u : b == 3 ? 0x3c000000u : 0u;
+                    v[0] = bh->lut[0][k & 255];
+                    v[1] = bh->lut[1][(k >> 8) & 255];
+                    v[2] = bh->lut[2][(k >> 16) & 255];
+                    v[3] = bh->lut[3][k >> 24];
+                }
+                kh2.x = (v[0] & 0xffffu) | (v[1] << 16);
+                kh2.y = (v[2] & 0xffffu) | (v[3] << 16);
+                kl2.x = (v[0] >> 16) | (v[1] & 0xffff0000u);
+                kl2.y = (v[2] >> 16) | (v[3] & 0xffff0000u);
+            }
+            *reinterpret_cast<uint2*>(w_oh + pr * 4) = o;
+            *reinterpret_cast<uint2*>(w_kh + pr * 4) = kh2;
+            *reinterpret_cast<uint2*>(w_kl + pr * 4) = kl2;
+        }
+    };
+    auto build_any = [&](const int s, const int t, const int nt) __attribute__((always_inline)) {
+        if constexpr (FOLD) build_window_f(s, t, nt);
+        else build_window(s, t, nt);
+    };
+    if ((int)blockIdx.x < n_sites) build_any(blockIdx.x, threadIdx.x, NW * 64);
     for (int s = blockIdx.x; s < n_sites; s += gridDim.x) {
         if (STAMP) tprev = hm_stamp();
         mk(0);
@@ -354,6 +524,11 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         mk(1);
 
         // conv1: window (planes B) -> planes A
+        if constexpr (FOLD)
+            Conv1F<NW, G::L1>::run(w_oh, w_kh, w_kl, reinterpret_cast<const half_t*>(W.c1f),
+                                   EpiPlanesC1<G::RS, G::L1>{a_hi, a_lo, W.c1f_bias, W.c1f_corr},
+                                   [&](int k) __attribute__((always_inline)) { mk(2 + k); });
+        else
         ConvH<NW, 8, G::KT1, 128, G::L1, G::WRS, 2, 4, 3>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[0]),
                                                              EpiPlanes<G::RS>{a_hi, a_lo, W.bias[0]}, [&](int k) __attribute__((always_inline)) { mk(2 + k); });
         mk(4);
@@ -386,7 +561,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
                                                             EpiGlobalF<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]}, [&](int k) __attribute__((always_inline)) { mk(14 + k); });
         mk(16);
         const int sn = s + gridDim.x;
-        if (sn < n_sites && (int)threadIdx.x >= 384) build_window(sn, threadIdx.x - 384, 128);
+        if (sn < n_sites && (int)threadIdx.x >= 384) build_any(sn, threadIdx.x - 384, 128);
         mk(17);
     }
     if (STAMP && (threadIdx.x & 63) == 0) {

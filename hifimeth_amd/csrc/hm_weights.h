@@ -24,6 +24,7 @@ struct PackedModel {
     std::vector<float> blob;
     size_t wfrag_off[9], bias_off[9], fc2_w_off, fc2_b_off, bn_off;
     size_t wfrag_h_off[9], bn_h_off;  // fp16 hi/lo data, offsets in floats like the others
+    size_t c1f_off, c1f_bias_off, c1f_corr_off;  // conv1 with bn0's one-hot half folded into the weights (see pack_model)
 };
 
 // <dir>/<name>.hmw, else <dir>/<name>.onnx (the reference's model_dir layout, mod_main.cpp:76,85,94)
