@@ -308,10 +308,16 @@ struct Conv1F {
         mark(1);
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
-            const int m = (wm * MTW + i) * 16 + li;
+            const int tile = wm * MTW + i;  // wave-uniform: only the first and the last tile hold a row that needs the correction
+            const int m = tile * 16 + li;
             if (m < M) {
+                if (tile == 0 || tile == (M - 1) / 16) {
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) epi(m, (nt0 + j) * 16 + 4 * lk, acc[i][j]);
+                    for (int j = 0; j < NTW; ++j) epi.edge(m, (nt0 + j) * 16 + 4 * lk, acc[i][j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) epi(m, (nt0 + j) * 16 + 4 * lk, acc[i][j]);
+                }
             }
         }
     }
@@ -325,15 +331,19 @@ struct EpiPlanesC1 {
     half_t* lo;
     const float* __restrict__ bias;
     const float* __restrict__ corr;  // [2][128]
-    __device__ __forceinline__ void operator()(int m, int col, f32x4 acc) const {
-        if (m == 0 || m == LOUT - 1) {
-            const float4 c = *reinterpret_cast<const float4*>(corr + (m ? 128 : 0) + col);
-            acc[0] -= c.x; acc[1] -= c.y; acc[2] -= c.z; acc[3] -= c.w;
-        }
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
         half4 h, l;
         split4(acc, h, l);
         *reinterpret_cast<half4*>(hi + (m + 1) * ORS + col) = h;
         *reinterpret_cast<half4*>(lo + (m + 1) * ORS + col) = l;
+    }
+    // tiles holding output row 0 or LOUT-1
+    __device__ __forceinline__ void edge(int m, int col, f32x4 acc) const {
+        if (m == 0 || m == LOUT - 1) {
+            const float4 c = *reinterpret_cast<const float4*>(corr + (m ? 128 : 0) + col);
+            acc[0] -= c.x; acc[1] -= c.y; acc[2] -= c.z; acc[3] -= c.w;
+        }
+        (*this)(m, col, acc);
     }
 };
 
