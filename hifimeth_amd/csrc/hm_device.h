@@ -55,6 +55,9 @@ struct BnTablesH {
     uint32_t hot[4];
     uint32_t zero[8];
     uint32_t lut[4][256];
+    // bn0 of a kinetics channel as one fma on the decoded frame count: value = frames * ka[c] + kb[c]
+    // (= ((frames / 952) - mean) / sd * gamma + beta up to fp32 rounding; used where the window never leaves the chip)
+    float ka[4], kb[4];
 };
 
 // per-context device weights: MFMA-fragment-packed conv/fc weights + biases

@@ -415,19 +415,28 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
     const BnTablesH* __restrict__ bh = W.bn_h;
 
     // window rows of site s -> planes B.  One thread per physical row: 8 halves (16 bytes) per plane.
-    auto build_window = [&](const int s, const int t, const int nt) __attribute__((always_inline)) {
-        int L = 0, qoff = 0, rev = 0;
-        int64_t bo = 0;
-        const float* src = nullptr;
+    // Descriptor of the site whose window is built next: fetched one layer ahead (see the site loop), so that the window
+    // build itself only waits for ONE level of global loads (the base / kinetics words), not for a chain of four.
+    struct SiteCtx {
+        int L, qoff, rev;
+        int64_t bo;
+    };
+    auto fetch_ctx = [&](const int s) __attribute__((always_inline)) {
+        SiteCtx c{0, 0, 0, 0};
         if (RAW) {
             const Site st = sites[s];
-            L = reads[st.read_idx].len;
-            bo = reads[st.read_idx].base_off;
-            qoff = st.qoff;
-            rev = bases[bo + qoff] == 2;
-        } else {
-            src = windows + (size_t)s * (KMER * FEATS);
+            c.L = reads[st.read_idx].len;
+            c.bo = reads[st.read_idx].base_off;
+            c.qoff = st.qoff;
+            c.rev = bases[c.bo + c.qoff] == 2;
         }
+        return c;
+    };
+    auto build_window = [&](const int s, const SiteCtx& cx, const int t, const int nt) __attribute__((always_inline)) {
+        const int L = cx.L, qoff = cx.qoff, rev = cx.rev;
+        const int64_t bo = cx.bo;
+        const float* src = nullptr;
+        if (!RAW) src = windows + (size_t)s * (KMER * FEATS);
         for (int pr = t; pr < G::WROWS; pr += nt) {
             const int w = pr - 1;
             uint32_t v[8];  // (hi | lo << 16) per channel
@@ -482,21 +491,42 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
     half_t* w_oh = b_hi;
     half_t* w_kh = b_hi + G::WROWS * 4;
     half_t* w_kl = b_hi + G::WROWS * 8;
-    auto build_window_f = [&](const int s, const int t, const int nt) __attribute__((always_inline)) {
-        const Site st = sites[s];
-        const int L = reads[st.read_idx].len;
-        const int64_t bo = reads[st.read_idx].base_off;
-        const int qoff = st.qoff;
-        const int rev = bases[bo + qoff] == 2;
+    // kinetics code (codev1 byte) -> bn0 value, split: frames = (((t & 63) + 64) << (t >> 6)) - 64 (bam_info.cpp:562-570),
+    // value = frames * ka + kb.  Arithmetic instead of a table gather: one level less in the chain of dependent loads.
+    // the eight constants are wave-uniform and read once: they stay in scalar registers for the whole kernel
+    float kac[4], kbc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        kac[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bh->ka[c])));
+        kbc[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bh->kb[c])));
+    }
+    auto kin_split = [&](const uint32_t k, uint2& hi2, uint2& lo2) __attribute__((always_inline)) {
+        float x[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t t = (k >> (8 * c)) & 255u;
+            const int frames = (int)(((t & 63u) + 64u) << (t >> 6)) - 64;
+            x[c] = fmaf((float)frames, kac[c], kbc[c]);
+        }
+        union { pk2 h; uint32_t u; } h01, h23;
+        h01.h = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
+        h23.h = __builtin_amdgcn_cvt_pkrtz(x[2], x[3]);
+        hi2 = make_uint2(h01.u, h23.u);
+        lo2 = make_uint2(split_lo2(h01.u, x[0], x[1]), split_lo2(h23.u, x[2], x[3]));
+    };
+    auto build_window_f = [&](const SiteCtx& cx, const int t, const int nt) __attribute__((always_inline)) {
+        const int L = cx.L, qoff = cx.qoff, rev = cx.rev;
+        const int64_t bo = cx.bo;
         for (int pr = t; pr < G::WROWS; pr += nt) {
             const int w = pr - 1;
             uint2 o = make_uint2(0u, 0u), kh2 = o, kl2 = o;
             if (w >= 0 && w < KMER) {
                 const int j = rev ? qoff + HK - w : qoff - HK + w;
-                uint32_t v[4];
                 if (j < 0 || j >= L) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = bh->zero[4 + c];
+                    kh2.x = (bh->zero[4] & 0xffffu) | (bh->zero[5] << 16);
+                    kh2.y = (bh->zero[6] & 0xffffu) | (bh->zero[7] << 16);
+                    kl2.x = (bh->zero[4] >> 16) | (bh->zero[5] & 0xffff0000u);
+                    kl2.y = (bh->zero[6] >> 16) | (bh->zero[7] & 0xffff0000u);
                 } else {
                     int b = bases[bo + j];
                     uint32_t k = kin[bo + j];
@@ -507,26 +537,20 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
                     // fp16 1.0 = 0x3c00 in the channel of the base
                     o.x = b == 0 ? 0x3c00u : b == 1 ? 0x3c000000u : 0u;
                     o.y = b == 2 ? 0x3c00u : b == 3 ? 0x3c000000u : 0u;
-                    v[0] = bh->lut[0][k & 255];
-                    v[1] = bh->lut[1][(k >> 8) & 255];
-                    v[2] = bh->lut[2][(k >> 16) & 255];
-                    v[3] = bh->lut[3][k >> 24];
+                    kin_split(k, kh2, kl2);
                 }
-                kh2.x = (v[0] & 0xffffu) | (v[1] << 16);
-                kh2.y = (v[2] & 0xffffu) | (v[3] << 16);
-                kl2.x = (v[0] >> 16) | (v[1] & 0xffff0000u);
-                kl2.y = (v[2] >> 16) | (v[3] & 0xffff0000u);
             }
             *reinterpret_cast<uint2*>(w_oh + pr * 4) = o;
             *reinterpret_cast<uint2*>(w_kh + pr * 4) = kh2;
             *reinterpret_cast<uint2*>(w_kl + pr * 4) = kl2;
         }
     };
-    auto build_any = [&](const int s, const int t, const int nt) __attribute__((always_inline)) {
-        if constexpr (FOLD) build_window_f(s, t, nt);
-        else build_window(s, t, nt);
+    auto build_any = [&](const int s, const SiteCtx& cx, const int t, const int nt) __attribute__((always_inline)) {
+        if constexpr (FOLD) build_window_f(cx, t, nt);
+        else build_window(s, cx, t, nt);
     };
-    if ((int)blockIdx.x < n_sites) build_any(blockIdx.x, threadIdx.x, NW * 64);
+    if ((int)blockIdx.x < n_sites) build_any(blockIdx.x, fetch_ctx(blockIdx.x), threadIdx.x, NW * 64);
+    SiteCtx ncx{0, 0, 0, 0};
     for (int s = blockIdx.x; s < n_sites; s += gridDim.x) {
         if (STAMP) tprev = hm_stamp();
         mk(0);
@@ -542,6 +566,13 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         ConvH<NW, 8, G::KT1, 128, G::L1, G::WRS, 2, 4, 3>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[0]),
                                                              EpiPlanes<G::RS>{a_hi, a_lo, W.bias[0]}, [&](int k) __attribute__((always_inline)) { mk(2 + k); });
         mk(4);
+        {   // next site's descriptor: requested here, three layers before the window build needs it
+            const int sn1 = s + gridDim.x;
+            if (sn1 < n_sites) {
+                ncx = fetch_ctx(sn1);
+                asm volatile("" : "+v"(ncx.rev));  // keeps the loads here instead of sinking them to the use after conv4
+            }
+        }
         zero_rows_h<128>(a_hi, a_lo, 0, G::L1 + 1, G::RS);
         __syncthreads();
         mk(5);
@@ -571,7 +602,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
                                                             EpiGlobalF<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]}, [&](int k) __attribute__((always_inline)) { mk(14 + k); });
         mk(16);
         const int sn = s + gridDim.x;
-        if (sn < n_sites && (int)threadIdx.x >= 384) build_any(sn, threadIdx.x - 384, 128);
+        if (sn < n_sites && (int)threadIdx.x >= 384) build_any(sn, ncx, threadIdx.x - 384, 128);
         mk(17);
     }
     if (STAMP && (threadIdx.x & 63) == 0) {

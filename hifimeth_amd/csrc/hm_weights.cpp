@@ -520,6 +520,9 @@ PackedModel pack_model(const HostModel& m) {
     for (int c = 0; c < 4; ++c) {
         bh.hot[c] = split(bn.hot[c]);
         for (int t = 0; t < 256; ++t) bh.lut[c][t] = split(bn.lut[c][t]);
+        const double sd = sqrt((double)m.bn_var[4 + c] + m.bn_eps), g = m.bn_gamma[4 + c];
+        bh.ka[c] = (float)(g / (sd * 952.0));
+        bh.kb[c] = (float)(m.bn_beta[4 + c] - m.bn_mean[4 + c] * g / sd);
     }
     align_blob(b);
     pk.bn_h_off = b.size();
