@@ -94,8 +94,8 @@ def cpu_baseline(reads, gpu_calls=None, budget_s=15.0):
 
 def roofline(precision, achieved, front_ms, front_launches, products=3.0):
     """Roofline of the dominant kernel. `achieved` = ALGORITHMIC TFLOP/s (2 FLOP per MAC of conv1..conv4).
-    The split-half kernel issues three fp16 MFMAs per algorithmic MAC (hi*hi + hi*lo + lo*hi) -- two for the one-hot half
-    of the 13-tap model's conv1, whose operand is exact fp16 -- so its executed rate is `products` (~2.9) x the
+    The split-half kernel issues three fp16 MFMAs per algorithmic MAC (hi*hi + hi*lo + lo*hi) -- two in conv1, whose
+    operand is exact fp16 once bn0 is folded into its weights -- so its executed rate is `products` (~2.76) x the
     algorithmic one; both are given, the peak is the fp16 dense MFMA peak."""
     base = {"bound": "mfma", "unit": "TFLOP/s", "achieved": achieved,
             "avg_launch_ms": front_ms / front_launches if front_launches else None, "launches": front_launches,
@@ -208,8 +208,10 @@ def main():
         front_launches = sum(tm["front_launches"])
         flop_front = sum(2.0 * MAC_FRONT[c] * tm["front_sites"][c] for c in range(3))
         achieved = flop_front / (front_ms * 1e-3) / 1e12 if front_ms > 0 else 0.0
-        # executed fp16 products per algorithmic MAC: 3, except the folded one-hot half (52 of the 104 K) of the CHH conv1: 2
-        exec_macs = sum((3.0 * MAC_FRONT[c] - (196 * 128 * 52 if c == 2 and args.precision >= 1 else 0)) * tm["front_sites"][c]
+        # executed fp16 products per algorithmic MAC: 3 (hi*hi, hi*lo, lo*hi), except conv1, whose operand is exact fp16 since
+        # bn0 is folded into its weights: 2
+        conv1_macs = {0: 197 * 128 * 88, 1: 197 * 128 * 88, 2: 196 * 128 * 104}
+        exec_macs = sum((3.0 * MAC_FRONT[c] - (conv1_macs[c] if args.precision >= 1 else 0)) * tm["front_sites"][c]
                         for c in range(3))
         products = exec_macs / max(1.0, sum(MAC_FRONT[c] * tm["front_sites"][c] for c in range(3)))
         gpu_ms = {k: tm[k] for k in ("prep_ms", "scan_ms", "emit_ms")}

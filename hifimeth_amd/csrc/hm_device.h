@@ -69,9 +69,9 @@ struct CtxWeights {
     const BnTables* bn;
     const uint16_t* wfrag_h[9];  // conv1..conv8, fc1 as fp16 hi/lo fragments: [n-tile][k-block of 32][plane][lane][8]
     const BnTablesH* bn_h;
-    // conv1 with the one-hot half of bn0 folded into the weights (front_kernel_h, staged-read path):
-    // fragments [n-tile][block: OH taps 0-7, OH taps 8-15, KIN taps 0-7, KIN taps 8-15][plane][lane][8],
-    // bias incl. the folded constant, and the constants to take back out at the two output rows that touch the conv padding
+    // conv1 with bn0 folded into the weights (front_kernel_h, staged-read path; hm_weights.cpp): fragments in the layout
+    // of wfrag_h[0], bias incl. the folded constants, and the constants to take back out at the two output rows that touch
+    // the conv padding.  The operand is then exact fp16: one-hot 0 / 1 and frame counts / 32.
     const uint16_t* c1f;
     const float* c1f_bias;  // [128]
     const float* c1f_corr;  // [2][128]: first output row, last output row

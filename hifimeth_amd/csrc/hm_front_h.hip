@@ -62,8 +62,10 @@ __device__ __forceinline__ void split4(const f32x4& v, half4& hi, half4& lo) {
 //   CIN == 8  : all 8 channels of tap 4*kb + lk
 // S sites may be stacked along M (tail kernel): row m -> (site = m / LOUT, p = m % LOUT), site stride ISS halves.
 // WLO = false drops the w_lo*x_hi pass: the layer then runs with plain fp16 WEIGHTS (BASELINE.json configs[4]).
+// XLO = false: the activations are exact fp16 (no lo plane; the w_hi*x_lo pass is dropped).  EDGE: the first and the last
+// position tile are written through epi.edge() (conv1 with bn0 folded into the weights, see hm_weights.cpp).
 template <int NW_, int CIN_, int KT_, int COUT_, int LOUT_, int IRS_, int WM_, int WN_, int BR_ = 2, int S_ = 1,
-          int ISS_ = 0, int ROW0_ = 0, bool WLO = true>
+          int ISS_ = 0, int ROW0_ = 0, bool WLO = true, bool XLO = true, bool EDGE = false>
 struct ConvH {
     static constexpr int NW = NW_, CIN = CIN_, KT = KT_, COUT = COUT_, LOUT = LOUT_, IRS = IRS_, WM = WM_, WN = WN_, BR = BR_;
     static constexpr int S = S_, ISS = ISS_, ROW0 = ROW0_;
@@ -130,7 +132,7 @@ struct ConvH {
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
             x[0][i][0] = *reinterpret_cast<const half8*>(in_hi + aoff[i]);
-            x[0][i][1] = *reinterpret_cast<const half8*>(in_lo + aoff[i]);
+            if (XLO) x[0][i][1] = *reinterpret_cast<const half8*>(in_lo + aoff[i]);
         }
 
         auto block = [&](auto rb_tag, auto ra_tag, const int kb) __attribute__((always_inline)) {
@@ -149,20 +151,22 @@ struct ConvH {
 #pragma unroll
                 for (int i = 0; i < MTW; ++i) {
                     x[RA ^ 1][i][0] = *reinterpret_cast<const half8*>(in_hi + bo + aoff[i]);
-                    x[RA ^ 1][i][1] = *reinterpret_cast<const half8*>(in_lo + bo + aoff[i]);
+                    if (XLO) x[RA ^ 1][i][1] = *reinterpret_cast<const half8*>(in_lo + bo + aoff[i]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             // the three partial products, outermost so that an accumulator is revisited only after
             // MTW*NTW other MFMAs (no back-to-back dependent MFMAs)
 #pragma unroll
-            for (int pr = 0; pr < (WLO ? 3 : 2); ++pr)
+            for (int pr = 0; pr < 3; ++pr) {
+                if ((pr == 1 && !XLO) || (pr == 2 && !WLO)) continue;  // (w_hi, x_hi), (w_hi, x_lo), (w_lo, x_hi)
 #pragma unroll
                 for (int i = 0; i < MTW; ++i)
 #pragma unroll
                     for (int j = 0; j < NTW; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[RB][j][pr == 2 ? 1 : 0], x[RA][i][pr == 1 ? 1 : 0],
                                                                            acc[i][j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         mark(0);
@@ -182,9 +186,17 @@ struct ConvH {
 
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
-            const int m = (wm * MTW + i) * 16 + li;
+            const int tile = wm * MTW + i;  // wave-uniform
+            const int m = tile * 16 + li;
             const bool full = WM == 1 ? (i + 1) * 16 <= M : false;
             if (full || m < M) {
+                if constexpr (EDGE) {
+                    if (tile == 0 || tile == (M - 1) / 16) {
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j) epi.edge(m, (wn * NTW + j) * 16 + 4 * lk, acc[i][j]);
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) epi(m, (wn * NTW + j) * 16 + 4 * lk, acc[i][j]);
             }
@@ -213,113 +225,6 @@ struct EpiGlobalF {
     __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
         *reinterpret_cast<float4*>(out + (size_t)m * COUT + col) =
             make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
-    }
-};
-
-// conv1 of the 13-tap (CHH) model on the staged-read path, with bn0's one-hot half folded into the weights
-// (hm_weights.cpp, "c1f"): the window is kept as three 8-byte-row arrays -- the one-hot channels as EXACT fp16 0/1
-// (no lo plane), the four kinetics channels as hi and lo planes -- and K is walked as 4 blocks of 8 taps x 4
-// channels: two one-hot blocks with 2 products each (w_hi*x, w_lo*x), two kinetics blocks with the usual 3.
-// 10 MFMAs per tile instead of 12.  Same 2x4 wave grid, accumulator layout and epilogue as ConvH.
-template <int NW, int LOUT>
-struct Conv1F {
-    static constexpr int WM = 2, WN = 4, COUT = 128, M = LOUT;
-    static constexpr int MT = (M + 15) / 16, MTW = (MT + WM - 1) / WM, NTW = COUT / 16 / WN;
-
-    template <class Epi, class Mark>
-    static __device__ __forceinline__ void run(const half_t* __restrict__ oh, const half_t* __restrict__ kh,
-                                               const half_t* __restrict__ kl, const half_t* __restrict__ wfrag, Epi epi,
-                                               Mark mark) {
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int wm = wave / WN, wn = wave % WN;
-        const int li = lane & 15, lk = lane >> 4;
-        int aoff[MTW];  // halves: row 2m + 2lk of the 4-half rows (taps 2lk, 2lk+1 of a block are one 16-byte read)
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            int m = (wm * MTW + i) * 16 + li;
-            m = m < M ? m : M - 1;
-            aoff[i] = (2 * m + 2 * lk) * 4;
-        }
-        const int nt0 = wn * NTW;
-        f32x4 acc[MTW][NTW];
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            const float4 bz = *reinterpret_cast<const float4*>(epi.bias + (nt0 + j) * 16 + 4 * lk);
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) acc[i][j] = f32x4{bz.x, bz.y, bz.z, bz.w};
-        }
-        // weights [n-tile][block][plane][lane] half8
-        const half8* wp = reinterpret_cast<const half8*>(wfrag) + (size_t)nt0 * 4 * 128 + lane;
-        half8 w[2][NTW][2];
-        half8 x[2][MTW][2];
-        auto load = [&](auto blk_tag, auto buf_tag) __attribute__((always_inline)) {
-            constexpr int B = decltype(blk_tag)::value, R = decltype(buf_tag)::value;
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                w[R][j][0] = wp[(size_t)(j * 4 + B) * 128];
-                w[R][j][1] = wp[(size_t)(j * 4 + B) * 128 + 64];
-            }
-            constexpr int ro = (B & 1) * 8 * 4;  // second block of a half starts 8 rows further down
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) {
-                if (B < 2) {
-                    x[R][i][0] = *reinterpret_cast<const half8*>(oh + ro + aoff[i]);
-                } else {
-                    x[R][i][0] = *reinterpret_cast<const half8*>(kh + ro + aoff[i]);
-                    x[R][i][1] = *reinterpret_cast<const half8*>(kl + ro + aoff[i]);
-                }
-            }
-        };
-        auto mma = [&](auto blk_tag, auto buf_tag) __attribute__((always_inline)) {
-            constexpr int B = decltype(blk_tag)::value, R = decltype(buf_tag)::value;
-            // one-hot blocks: (w_hi, x), (w_lo, x); kinetics blocks: (w_hi, x_hi), (w_hi, x_lo), (w_lo, x_hi)
-#pragma unroll
-            for (int pr = 0; pr < (B < 2 ? 2 : 3); ++pr)
-#pragma unroll
-                for (int i = 0; i < MTW; ++i)
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j) {
-                        const int wpl = B < 2 ? pr : (pr == 2 ? 1 : 0), xpl = B < 2 ? 0 : (pr == 1 ? 1 : 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[R][j][wpl], x[R][i][xpl], acc[i][j], 0, 0, 0);
-                    }
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
-        using I3 = std::integral_constant<int, 3>;
-        load(I0{}, I0{});
-        mark(0);
-        load(I1{}, I1{});
-        __builtin_amdgcn_sched_barrier(0);
-        mma(I0{}, I0{});
-        __builtin_amdgcn_sched_barrier(0);
-        load(I2{}, I0{});
-        __builtin_amdgcn_sched_barrier(0);
-        mma(I1{}, I1{});
-        __builtin_amdgcn_sched_barrier(0);
-        load(I3{}, I1{});
-        __builtin_amdgcn_sched_barrier(0);
-        mma(I2{}, I0{});
-        __builtin_amdgcn_sched_barrier(0);
-        mma(I3{}, I1{});
-        __builtin_amdgcn_sched_barrier(0);
-        mark(1);
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            const int tile = wm * MTW + i;  // wave-uniform: only the first and the last tile hold a row that needs the correction
-            const int m = tile * 16 + li;
-            if (m < M) {
-                if (tile == 0 || tile == (M - 1) / 16) {
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j) epi.edge(m, (nt0 + j) * 16 + 4 * lk, acc[i][j]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j) epi(m, (nt0 + j) * 16 + 4 * lk, acc[i][j]);
-                }
-            }
-        }
     }
 };
 
@@ -486,63 +391,38 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         }
     };
 
-    // folded layout (FOLD): three arrays of 4-half rows in region B -- one-hot as exact 0/1, kinetics hi, kinetics lo
-    constexpr bool FOLD = RAW && K1 == 13;
-    half_t* w_oh = b_hi;
-    half_t* w_kh = b_hi + G::WROWS * 4;
-    half_t* w_kl = b_hi + G::WROWS * 8;
-    // kinetics code (codev1 byte) -> bn0 value, split: frames = (((t & 63) + 64) << (t >> 6)) - 64 (bam_info.cpp:562-570),
-    // value = frames * ka + kb.  Arithmetic instead of a table gather: one level less in the chain of dependent loads.
-    // the eight constants are wave-uniform and read once: they stay in scalar registers for the whole kernel
-    float kac[4], kbc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        kac[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bh->ka[c])));
-        kbc[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bh->kb[c])));
-    }
-    auto kin_split = [&](const uint32_t k, uint2& hi2, uint2& lo2) __attribute__((always_inline)) {
-        float x[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t t = (k >> (8 * c)) & 255u;
-            const int frames = (int)(((t & 63u) + 64u) << (t >> 6)) - 64;
-            x[c] = fmaf((float)frames, kac[c], kbc[c]);
-        }
-        union { pk2 h; uint32_t u; } h01, h23;
-        h01.h = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
-        h23.h = __builtin_amdgcn_cvt_pkrtz(x[2], x[3]);
-        hi2 = make_uint2(h01.u, h23.u);
-        lo2 = make_uint2(split_lo2(h01.u, x[0], x[1]), split_lo2(h23.u, x[2], x[3]));
-    };
+    // folded layout (FOLD, every staged-read launch): bn0 lives in conv1's weights, so a window row is 8 EXACT halves --
+    // the one-hot base (0 / 1) and the four decoded frame counts / 32 (integers <= 952 scaled by a power of two) -- in one plane; rows outside the read
+    // and the conv padding are all zeros
+    constexpr bool FOLD = RAW;
     auto build_window_f = [&](const SiteCtx& cx, const int t, const int nt) __attribute__((always_inline)) {
         const int L = cx.L, qoff = cx.qoff, rev = cx.rev;
         const int64_t bo = cx.bo;
         for (int pr = t; pr < G::WROWS; pr += nt) {
             const int w = pr - 1;
-            uint2 o = make_uint2(0u, 0u), kh2 = o, kl2 = o;
-            if (w >= 0 && w < KMER) {
-                const int j = rev ? qoff + HK - w : qoff - HK + w;
-                if (j < 0 || j >= L) {
-                    kh2.x = (bh->zero[4] & 0xffffu) | (bh->zero[5] << 16);
-                    kh2.y = (bh->zero[6] & 0xffffu) | (bh->zero[7] << 16);
-                    kl2.x = (bh->zero[4] >> 16) | (bh->zero[5] & 0xffff0000u);
-                    kl2.y = (bh->zero[6] >> 16) | (bh->zero[7] & 0xffff0000u);
-                } else {
-                    int b = bases[bo + j];
-                    uint32_t k = kin[bo + j];
-                    if (rev) {
-                        if (b < 4) b = 3 - b;
-                        k = (k >> 16) | (k << 16);
-                    }
-                    // fp16 1.0 = 0x3c00 in the channel of the base
-                    o.x = b == 0 ? 0x3c00u : b == 1 ? 0x3c000000u : 0u;
-                    o.y = b == 2 ? 0x3c00u : b == 3 ? 0x3c000000u : 0u;
-                    kin_split(k, kh2, kl2);
+            uint4 row = make_uint4(0u, 0u, 0u, 0u);
+            const int j = rev ? qoff + HK - w : qoff - HK + w;
+            if (w >= 0 && w < KMER && j >= 0 && j < L) {
+                int b = bases[bo + j];
+                uint32_t k = kin[bo + j];
+                if (rev) {
+                    if (b < 4) b = 3 - b;
+                    k = (k >> 16) | (k << 16);
                 }
+                // fp16 1.0 = 0x3c00 in the channel of the base
+                row.x = b == 0 ? 0x3c00u : b == 1 ? 0x3c000000u : 0u;
+                row.y = b == 2 ? 0x3c00u : b == 3 ? 0x3c000000u : 0u;
+                // codev1 byte t -> frames = (((t & 63) + 64) << (t >> 6)) - 64 (bam_info.cpp:562-570), exact in fp16
+                half_t f[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t tt = (k >> (8 * c)) & 255u;
+                    f[c] = (half_t)((float)((int)(((tt & 63u) + 64u) << (tt >> 6)) - 64) * 0.03125f);  // frames / 32, exact
+                }
+                row.z = (uint32_t)__builtin_bit_cast(uint16_t, f[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, f[1]) << 16);
+                row.w = (uint32_t)__builtin_bit_cast(uint16_t, f[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, f[3]) << 16);
             }
-            *reinterpret_cast<uint2*>(w_oh + pr * 4) = o;
-            *reinterpret_cast<uint2*>(w_kh + pr * 4) = kh2;
-            *reinterpret_cast<uint2*>(w_kl + pr * 4) = kl2;
+            *reinterpret_cast<uint4*>(b_hi + pr * G::WRS) = row;
         }
     };
     auto build_any = [&](const int s, const SiteCtx& cx, const int t, const int nt) __attribute__((always_inline)) {
@@ -559,9 +439,9 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
 
         // conv1: window (planes B) -> planes A
         if constexpr (FOLD)
-            Conv1F<NW, G::L1>::run(w_oh, w_kh, w_kl, reinterpret_cast<const half_t*>(W.c1f),
-                                   EpiPlanesC1<G::RS, G::L1>{a_hi, a_lo, W.c1f_bias, W.c1f_corr},
-                                   [&](int k) __attribute__((always_inline)) { mk(2 + k); });
+            ConvH<NW, 8, G::KT1, 128, G::L1, G::WRS, 2, 4, 3, 1, 0, 0, true, false, true>::run(
+                b_hi, b_hi, reinterpret_cast<const half_t*>(W.c1f), EpiPlanesC1<G::RS, G::L1>{a_hi, a_lo, W.c1f_bias, W.c1f_corr},
+                [&](int k) __attribute__((always_inline)) { mk(2 + k); });
         else
         ConvH<NW, 8, G::KT1, 128, G::L1, G::WRS, 2, 4, 3>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[0]),
                                                              EpiPlanes<G::RS>{a_hi, a_lo, W.bias[0]}, [&](int k) __attribute__((always_inline)) { mk(2 + k); });

@@ -529,26 +529,31 @@ PackedModel pack_model(const HostModel& m) {
     b.resize(b.size() + (sizeof(BnTablesH) + 3) / 4);
     memcpy(b.data() + pk.bn_h_off, &bh, sizeof bh);
 
-    // ---- conv1 with bn0's one-hot half folded into the weights ---------------------------------------------
-    // bn0 maps a one-hot channel c to hot[c] (base matches) or zero[c] (it does not, or the row lies outside the
-    // read): value = zero[c] + (hot[c] - zero[c]) * onehot.  So  sum_t W[co][c][t] * value  =  const[co] +
-    // sum_t (W[co][c][t] * (hot[c] - zero[c])) * onehot, with onehot in {0, 1} EXACT in fp16 (no lo plane, two MFMAs
-    // instead of three).  The constant goes into the bias; the two output rows whose taps reach the conv's own zero
-    // padding (window rows -1 and 401, which are 0 AFTER bn0) get their share of it taken back (c1f_corr).
+    // ---- conv1 with bn0 folded into the weights ------------------------------------------------------------------
+    // bn0 is affine per channel.  One-hot channel c: value = zero[c] + (hot[c] - zero[c]) * onehot, onehot in {0, 1}.
+    // Kinetics channel c: value = kb[c] + ka[c] * frames with frames = decoded codev1 byte, an INTEGER in 0..952.  Both
+    // operands are EXACT in fp16 (no lo plane: two MFMAs per product instead of three); the weights absorb the slopes,
+    // the constants go into the bias.  The conv's own zero padding (window rows -1 and 401, 0 AFTER bn0) must not
+    // receive the constant: the two output rows that reach it get their share taken back (c1f_corr).
+    // Fragment layout as wfrag_h[0]: [n-tile][k-block of 4 taps][plane][lane][8 = channels of tap 4*kb + (lane >> 4)].
     {
-        const int k1 = m.kernel[0], L1 = (401 + 2 - k1) / 2 + 1;
+        const int k1 = m.kernel[0], L1 = (401 + 2 - k1) / 2 + 1, KB = (k1 * 8 + 31) / 32;
         const std::vector<float>& w = m.conv_w[0];  // [128][8][k1]
         auto W = [&](int co, int c, int t) { return w[((size_t)co * 8 + c) * k1 + t]; };
-        std::vector<uint16_t> hw((size_t)8 * 4 * 2 * 64 * 8);
+        // the frame counts reach the MFMA as frames / 32 (still exact in fp16: a power-of-two scale) and the weights take the
+        // x32: ka ~ 2^-5, and weights that small would leave their fp16 lo halves in the subnormal range (4 bits instead of 11)
+        auto slope = [&](int c) { return c < 4 ? bn.hot[c] - bn.zero[c] : bh.ka[c - 4] * 32.0f; };
+        auto konst = [&](int c) { return c < 4 ? (double)bn.zero[c] : (double)bh.kb[c - 4]; };
+        std::vector<uint16_t> hw((size_t)8 * KB * 2 * 64 * 8);
         size_t o = 0;
         for (int nt = 0; nt < 8; ++nt)
-            for (int blk = 0; blk < 4; ++blk)
+            for (int kb = 0; kb < KB; ++kb)
                 for (int plane = 0; plane < 2; ++plane)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int j = 0; j < 8; ++j) {
-                            const int tap = 8 * (blk & 1) + 2 * (lane >> 4) + (j >> 2), ch = j & 3, co = nt * 16 + (lane & 15);
+                            const int tap = 4 * kb + (lane >> 4), co = nt * 16 + (lane & 15);
                             uint32_t hl = 0;
-                            if (tap < k1) hl = split(blk < 2 ? W(co, ch, tap) * (bn.hot[ch] - bn.zero[ch]) : W(co, 4 + ch, tap));
+                            if (tap < k1) hl = split(W(co, j, tap) * slope(j));
                             hw[o++] = (uint16_t)(plane ? hl >> 16 : hl & 0xffffu);
                         }
         align_blob(b);
@@ -560,7 +565,7 @@ PackedModel pack_model(const HostModel& m) {
         for (int co = 0; co < 128; ++co) {
             double s = m.conv_b[0][co];
             for (int t = 0; t < k1; ++t)
-                for (int c = 0; c < 4; ++c) s += (double)W(co, c, t) * bn.zero[c];
+                for (int c = 0; c < 8; ++c) s += (double)W(co, c, t) * konst(c);
             b.push_back((float)s);
         }
         align_blob(b);
@@ -571,7 +576,7 @@ PackedModel pack_model(const HostModel& m) {
                 for (int t = 0; t < k1; ++t) {
                     const int wrow = 2 * (row ? L1 - 1 : 0) + t - 1;  // window row reached by tap t
                     if (wrow >= 0 && wrow < 401) continue;
-                    for (int c = 0; c < 4; ++c) s += (double)W(co, c, t) * bn.zero[c];
+                    for (int c = 0; c < 8; ++c) s += (double)W(co, c, t) * konst(c);
                 }
                 b.push_back((float)s);
             }
