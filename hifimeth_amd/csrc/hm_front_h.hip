@@ -64,8 +64,12 @@ __device__ __forceinline__ void split4(const f32x4& v, half4& hi, half4& lo) {
 // WLO = false drops the w_lo*x_hi pass: the layer then runs with plain fp16 WEIGHTS (BASELINE.json configs[4]).
 // XLO = false: the activations are exact fp16 (no lo plane; the w_hi*x_lo pass is dropped).  EDGE: the first and the last
 // position tile are written through epi.edge() (conv1 with bn0 folded into the weights, see hm_weights.cpp).
+// KSTACK = K1 > 0 (conv1 with an exact operand): the hi and the lo halves of the weights are stacked along K as 2*K1
+// "taps" over the SAME window rows -- tap slot t < K1 holds w_hi of tap t, slot K1 + t holds w_lo of tap t -- so one MFMA
+// product per block covers both and only ceil(2*K1 / 4) blocks are needed (7 instead of 4 x 2 for K1 = 13).  KT_ is then
+// the number of tap slots (a multiple of 4) and the weights have no plane dimension.
 template <int NW_, int CIN_, int KT_, int COUT_, int LOUT_, int IRS_, int WM_, int WN_, int BR_ = 2, int S_ = 1,
-          int ISS_ = 0, int ROW0_ = 0, bool WLO = true, bool XLO = true, bool EDGE = false>
+          int ISS_ = 0, int ROW0_ = 0, bool WLO = true, bool XLO = true, bool EDGE = false, int KSTACK = 0>
 struct ConvH {
     static constexpr int NW = NW_, CIN = CIN_, KT = KT_, COUT = COUT_, LOUT = LOUT_, IRS = IRS_, WM = WM_, WN = WN_, BR = BR_;
     static constexpr int S = S_, ISS = ISS_, ROW0 = ROW0_;
@@ -100,7 +104,14 @@ struct ConvH {
         if (WM * WN < NW && wave >= WM * WN) return;
         const int wm = WM == 1 ? 0 : wave / WN, wn = WM == 1 ? wave : wave % WN;
         const int li = lane & 15, lk = lane >> 4;
-        const int lk_off = CIN == 8 ? lk * IRS : 8 * lk;
+        const int lk_off = KSTACK ? 0 : CIN == 8 ? lk * IRS : 8 * lk;
+        constexpr int WSTR = KSTACK ? 64 : 128;  // half8 per (n-tile, k-block): one plane when stacked
+        // window row of tap slot 4*kb + lk when stacked: slots >= K1 walk the same rows again with the lo halves
+        auto stack_off = [&](int kb) __attribute__((always_inline)) {
+            int t = 4 * kb + lk;
+            t = t >= 2 * KSTACK ? 0 : t >= KSTACK ? t - KSTACK : t;
+            return t * IRS;
+        };
 
         int aoff[MTW];
 #pragma unroll
@@ -119,20 +130,23 @@ struct ConvH {
         }
 
         // weights: [n-tile][k-block][plane hi/lo][lane] half8
-        const half8* wp = reinterpret_cast<const half8*>(wfrag) + (size_t)(wn * NTW) * KB * 128 + lane;
+        const half8* wp = reinterpret_cast<const half8*>(wfrag) + (size_t)(wn * NTW) * KB * WSTR + lane;
         half8 wq[BR][NTW][2];
         half8 x[2][MTW][2];
 #pragma unroll
         for (int r = 0; r < BR - 1; ++r)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                wq[r][j][0] = wp[(size_t)(j * KB + r) * 128];
-                if (WLO) wq[r][j][1] = wp[(size_t)(j * KB + r) * 128 + 64];
+                wq[r][j][0] = wp[(size_t)(j * KB + r) * WSTR];
+                if (WLO && !KSTACK) wq[r][j][1] = wp[(size_t)(j * KB + r) * WSTR + 64];
             }
+        {
+            const int bo0 = KSTACK ? stack_off(0) : 0;
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            x[0][i][0] = *reinterpret_cast<const half8*>(in_hi + aoff[i]);
-            if (XLO) x[0][i][1] = *reinterpret_cast<const half8*>(in_lo + aoff[i]);
+            for (int i = 0; i < MTW; ++i) {
+                x[0][i][0] = *reinterpret_cast<const half8*>(in_hi + bo0 + aoff[i]);
+                if (XLO) x[0][i][1] = *reinterpret_cast<const half8*>(in_lo + bo0 + aoff[i]);
+            }
         }
 
         auto block = [&](auto rb_tag, auto ra_tag, const int kb) __attribute__((always_inline)) {
@@ -142,12 +156,13 @@ struct ConvH {
                 const int kw = kb + BR - 1 < KB ? kb + BR - 1 : KB - 1;
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
-                    wq[(RB + BR - 1) % BR][j][0] = wp[(size_t)(j * KB + kw) * 128];
-                    if (WLO) wq[(RB + BR - 1) % BR][j][1] = wp[(size_t)(j * KB + kw) * 128 + 64];
+                    wq[(RB + BR - 1) % BR][j][0] = wp[(size_t)(j * KB + kw) * WSTR];
+                    if (WLO && !KSTACK) wq[(RB + BR - 1) % BR][j][1] = wp[(size_t)(j * KB + kw) * WSTR + 64];
                 }
             }
             {
-                const int bo = block_off(kb + 1 < KB ? kb + 1 : KB - 1);
+                const int kn = kb + 1 < KB ? kb + 1 : KB - 1;
+                const int bo = KSTACK ? stack_off(kn) : block_off(kn);
 #pragma unroll
                 for (int i = 0; i < MTW; ++i) {
                     x[RA ^ 1][i][0] = *reinterpret_cast<const half8*>(in_hi + bo + aoff[i]);
@@ -159,7 +174,7 @@ struct ConvH {
             // MTW*NTW other MFMAs (no back-to-back dependent MFMAs)
 #pragma unroll
             for (int pr = 0; pr < 3; ++pr) {
-                if ((pr == 1 && !XLO) || (pr == 2 && !WLO)) continue;  // (w_hi, x_hi), (w_hi, x_lo), (w_lo, x_hi)
+                if ((pr == 1 && !XLO) || (pr == 2 && (!WLO || KSTACK))) continue;  // (w_hi, x_hi), (w_hi, x_lo), (w_lo, x_hi)
 #pragma unroll
                 for (int i = 0; i < MTW; ++i)
 #pragma unroll
@@ -439,7 +454,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
 
         // conv1: window (planes B) -> planes A
         if constexpr (FOLD)
-            ConvH<NW, 8, G::KT1, 128, G::L1, G::WRS, 2, 4, 3, 1, 0, 0, true, false, true>::run(
+            ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, G::L1, G::WRS, 2, 4, 3, 1, 0, 0, true, false, true, K1>::run(
                 b_hi, b_hi, reinterpret_cast<const half_t*>(W.c1f), EpiPlanesC1<G::RS, G::L1>{a_hi, a_lo, W.c1f_bias, W.c1f_corr},
                 [&](int k) __attribute__((always_inline)) { mk(2 + k); });
         else

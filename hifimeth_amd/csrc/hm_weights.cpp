@@ -535,27 +535,29 @@ PackedModel pack_model(const HostModel& m) {
     // operands are EXACT in fp16 (no lo plane: two MFMAs per product instead of three); the weights absorb the slopes,
     // the constants go into the bias.  The conv's own zero padding (window rows -1 and 401, 0 AFTER bn0) must not
     // receive the constant: the two output rows that reach it get their share taken back (c1f_corr).
-    // Fragment layout as wfrag_h[0]: [n-tile][k-block of 4 taps][plane][lane][8 = channels of tap 4*kb + (lane >> 4)].
+    // The operand being exact, the hi and lo halves of the weights are STACKED along K as 2*k1 tap slots over the same
+    // window rows (slot t < k1: w_hi of tap t; slot k1 + t: w_lo of tap t): ceil(2*k1 / 4) k-blocks with one product each.
+    // Fragment layout: [n-tile][k-block of 4 slots][lane][8 = channels of slot 4*kb + (lane >> 4)].
     {
-        const int k1 = m.kernel[0], L1 = (401 + 2 - k1) / 2 + 1, KB = (k1 * 8 + 31) / 32;
+        const int k1 = m.kernel[0], L1 = (401 + 2 - k1) / 2 + 1, KB = (2 * k1 + 3) / 4;
         const std::vector<float>& w = m.conv_w[0];  // [128][8][k1]
         auto W = [&](int co, int c, int t) { return w[((size_t)co * 8 + c) * k1 + t]; };
         // the frame counts reach the MFMA as frames / 32 (still exact in fp16: a power-of-two scale) and the weights take the
         // x32: ka ~ 2^-5, and weights that small would leave their fp16 lo halves in the subnormal range (4 bits instead of 11)
         auto slope = [&](int c) { return c < 4 ? bn.hot[c] - bn.zero[c] : bh.ka[c - 4] * 32.0f; };
         auto konst = [&](int c) { return c < 4 ? (double)bn.zero[c] : (double)bh.kb[c - 4]; };
-        std::vector<uint16_t> hw((size_t)8 * KB * 2 * 64 * 8);
+        std::vector<uint16_t> hw((size_t)8 * KB * 64 * 8);
         size_t o = 0;
         for (int nt = 0; nt < 8; ++nt)
             for (int kb = 0; kb < KB; ++kb)
-                for (int plane = 0; plane < 2; ++plane)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j) {
-                            const int tap = 4 * kb + (lane >> 4), co = nt * 16 + (lane & 15);
-                            uint32_t hl = 0;
-                            if (tap < k1) hl = split(W(co, j, tap) * slope(j));
-                            hw[o++] = (uint16_t)(plane ? hl >> 16 : hl & 0xffffu);
-                        }
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int slot = 4 * kb + (lane >> 4), plane = slot >= k1, tap = slot - plane * k1;
+                        const int co = nt * 16 + (lane & 15);
+                        uint32_t hl = 0;
+                        if (slot < 2 * k1) hl = split(W(co, j, tap) * slope(j));
+                        hw[o++] = (uint16_t)(plane ? hl >> 16 : hl & 0xffffu);
+                    }
         align_blob(b);
         pk.c1f_off = b.size();
         b.resize(b.size() + (hw.size() * 2 + 3) / 4);
