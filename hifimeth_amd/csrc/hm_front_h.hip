@@ -454,7 +454,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
 
         // conv1: window (planes B) -> planes A
         if constexpr (FOLD)
-            ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, G::L1, G::WRS, 2, 4, 3, 1, 0, 0, true, false, true, K1>::run(
+            ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, G::L1, G::WRS, 1, 8, 3, 1, 0, 0, true, false, true, K1>::run(
                 b_hi, b_hi, reinterpret_cast<const half_t*>(W.c1f), EpiPlanesC1<G::RS, G::L1>{a_hi, a_lo, W.c1f_bias, W.c1f_corr},
                 [&](int k) __attribute__((always_inline)) { mk(2 + k); });
         else
