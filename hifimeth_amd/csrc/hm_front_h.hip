@@ -413,31 +413,49 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
     auto build_window_f = [&](const SiteCtx& cx, const int t, const int nt) __attribute__((always_inline)) {
         const int L = cx.L, qoff = cx.qoff, rev = cx.rev;
         const int64_t bo = cx.bo;
-        for (int pr = t; pr < G::WROWS; pr += nt) {
-            const int w = pr - 1;
-            uint4 row = make_uint4(0u, 0u, 0u, 0u);
-            const int j = rev ? qoff + HK - w : qoff - HK + w;
-            if (w >= 0 && w < KMER && j >= 0 && j < L) {
-                int b = bases[bo + j];
-                uint32_t k = kin[bo + j];
-                if (rev) {
-                    if (b < 4) b = 3 - b;
-                    k = (k >> 16) | (k << 16);
-                }
-                // fp16 1.0 = 0x3c00 in the channel of the base
-                row.x = b == 0 ? 0x3c00u : b == 1 ? 0x3c000000u : 0u;
-                row.y = b == 2 ? 0x3c00u : b == 3 ? 0x3c000000u : 0u;
-                // codev1 byte t -> frames = (((t & 63) + 64) << (t >> 6)) - 64 (bam_info.cpp:562-570), exact in fp16
-                half_t f[4];
+        // up to 4 rows per thread (two waves beside conv4, whose weight stream keeps the vector-memory pipe busy): the
+        // base / kinetics words of all rows are requested first, so the rows share one load latency
+        constexpr int NRW = 4;
+        int bb[NRW];
+        uint32_t kk[NRW];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint32_t tt = (k >> (8 * c)) & 255u;
-                    f[c] = (half_t)((float)((int)(((tt & 63u) + 64u) << (tt >> 6)) - 64) * 0.03125f);  // frames / 32, exact
-                }
-                row.z = (uint32_t)__builtin_bit_cast(uint16_t, f[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, f[1]) << 16);
-                row.w = (uint32_t)__builtin_bit_cast(uint16_t, f[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, f[3]) << 16);
+        for (int r = 0; r < NRW; ++r) {
+            const int pr = t + r * nt, w = pr - 1;
+            const int j = rev ? qoff + HK - w : qoff - HK + w;
+            bb[r] = -1;  // zeros: conv padding, beyond the window, or outside the read
+            kk[r] = 0;
+            if (pr < G::WROWS && w >= 0 && w < KMER && j >= 0 && j < L) {
+                bb[r] = bases[bo + j];
+                kk[r] = kin[bo + j];
             }
-            *reinterpret_cast<uint4*>(b_hi + pr * G::WRS) = row;
+        }
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) {
+            const int pr = t + r * nt;
+            if (pr < G::WROWS) {
+                uint4 row = make_uint4(0u, 0u, 0u, 0u);
+                if (bb[r] >= 0) {
+                    int b = bb[r];
+                    uint32_t k = kk[r];
+                    if (rev) {
+                        if (b < 4) b = 3 - b;
+                        k = (k >> 16) | (k << 16);
+                    }
+                    // fp16 1.0 = 0x3c00 in the channel of the base
+                    row.x = b == 0 ? 0x3c00u : b == 1 ? 0x3c000000u : 0u;
+                    row.y = b == 2 ? 0x3c00u : b == 3 ? 0x3c000000u : 0u;
+                    // codev1 byte t -> frames = (((t & 63) + 64) << (t >> 6)) - 64 (bam_info.cpp:562-570); frames / 32 is exact in fp16
+                    half_t f[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t tt = (k >> (8 * c)) & 255u;
+                        f[c] = (half_t)((float)((int)(((tt & 63u) + 64u) << (tt >> 6)) - 64) * 0.03125f);
+                    }
+                    row.z = (uint32_t)__builtin_bit_cast(uint16_t, f[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, f[1]) << 16);
+                    row.w = (uint32_t)__builtin_bit_cast(uint16_t, f[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, f[3]) << 16);
+                }
+                *reinterpret_cast<uint4*>(b_hi + pr * G::WRS) = row;
+            }
         }
     };
     auto build_any = [&](const int s, const SiteCtx& cx, const int t, const int nt) __attribute__((always_inline)) {
