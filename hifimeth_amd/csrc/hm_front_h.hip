@@ -332,7 +332,6 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
     half_t* b_hi = smem + 2 * G::PA;
     half_t* b_lo = smem + 2 * G::PA + G::PB;
     const BnTables* __restrict__ bn = W.bn;
-    const BnTablesH* __restrict__ bh = W.bn_h;
 
     // window rows of site s -> planes B.  One thread per physical row: 8 halves (16 bytes) per plane.
     // Descriptor of the site whose window is built next: fetched one layer ahead (see the site loop), so that the window
@@ -352,44 +351,21 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         }
         return c;
     };
-    auto build_window = [&](const int s, const SiteCtx& cx, const int t, const int nt) __attribute__((always_inline)) {
-        const int L = cx.L, qoff = cx.qoff, rev = cx.rev;
-        const int64_t bo = cx.bo;
-        const float* src = nullptr;
-        if (!RAW) src = windows + (size_t)s * (KMER * FEATS);
+    // caller-supplied float windows (the hm_cnn_logits / hm_debug_layer seam): bn0 in fp32, then split into planes B
+    auto build_window = [&](const int s, const int t, const int nt) __attribute__((always_inline)) {
+        const float* src = windows + (size_t)s * (KMER * FEATS);
         for (int pr = t; pr < G::WROWS; pr += nt) {
             const int w = pr - 1;
             uint32_t v[8];  // (hi | lo << 16) per channel
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] = 0u;
             if (w >= 0 && w < KMER) {
-                if (RAW) {
-                    const int j = rev ? qoff + HK - w : qoff - HK + w;
-                    if (j < 0 || j >= L) {
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) v[c] = bh->zero[c];
-                    } else {
-                        int b = bases[bo + j];
-                        uint32_t k = kin[bo + j];
-                        if (rev) {
-                            if (b < 4) b = 3 - b;
-                            k = (k >> 16) | (k << 16);
-                        }
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = b == c ? bh->hot[c] : bh->zero[c];
-                        v[4] = bh->lut[0][k & 255];
-                        v[5] = bh->lut[1][(k >> 8) & 255];
-                        v[6] = bh->lut[2][(k >> 16) & 255];
-                        v[7] = bh->lut[3][k >> 24];
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const float x = (src[w * 8 + c] - bn->mean[c]) / bn->sd[c] * bn->gamma[c] + bn->beta[c];
-                        const half_t h = (half_t)x;
-                        const half_t l = (half_t)(x - (float)h);
-                        v[c] = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
-                    }
+                for (int c = 0; c < 8; ++c) {
+                    const float x = (src[w * 8 + c] - bn->mean[c]) / bn->sd[c] * bn->gamma[c] + bn->beta[c];
+                    const half_t h = (half_t)x;
+                    const half_t l = (half_t)(x - (float)h);
+                    v[c] = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
                 }
             }
             uint4 ph, pl;
@@ -407,8 +383,8 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
     };
 
     // folded layout (FOLD, every staged-read launch): bn0 lives in conv1's weights, so a window row is 8 EXACT halves --
-    // the one-hot base (0 / 1) and the four decoded frame counts / 32 (integers <= 952 scaled by a power of two) -- in one plane; rows outside the read
-    // and the conv padding are all zeros
+    // the one-hot base (0 / 1) and the four decoded frame counts / 32 (integers <= 952 scaled by a power of two) -- in one
+    // plane; rows outside the read and the conv padding are all zeros
     constexpr bool FOLD = RAW;
     auto build_window_f = [&](const SiteCtx& cx, const int t, const int nt) __attribute__((always_inline)) {
         const int L = cx.L, qoff = cx.qoff, rev = cx.rev;
@@ -460,7 +436,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
     };
     auto build_any = [&](const int s, const SiteCtx& cx, const int t, const int nt) __attribute__((always_inline)) {
         if constexpr (FOLD) build_window_f(cx, t, nt);
-        else build_window(s, cx, t, nt);
+        else build_window(s, t, nt);
     };
     if ((int)blockIdx.x < n_sites) build_any(blockIdx.x, fetch_ctx(blockIdx.x), threadIdx.x, NW * 64);
     SiteCtx ncx{0, 0, 0, 0};
