@@ -69,7 +69,7 @@ __device__ __forceinline__ void split4(const f32x4& v, half4& hi, half4& lo) {
 // product per block covers both and only ceil(2*K1 / 4) blocks are needed (7 instead of 4 x 2 for K1 = 13).  KT_ is then
 // the number of tap slots (a multiple of 4) and the weights have no plane dimension.
 template <int NW_, int CIN_, int KT_, int COUT_, int LOUT_, int IRS_, int WM_, int WN_, int BR_ = 2, int S_ = 1,
-          int ISS_ = 0, int ROW0_ = 0, bool WLO = true, bool XLO = true, bool EDGE = false, int KSTACK = 0>
+          int ISS_ = 0, int ROW0_ = 0, bool WLO = true, bool XLO = true, bool EDGE = false, int KSTACK = 0, bool ILV = false>
 struct ConvH {
     static constexpr int NW = NW_, CIN = CIN_, KT = KT_, COUT = COUT_, LOUT = LOUT_, IRS = IRS_, WM = WM_, WN = WN_, BR = BR_;
     static constexpr int S = S_, ISS = ISS_, ROW0 = ROW0_;
@@ -169,7 +169,7 @@ struct ConvH {
                     if (XLO) x[RA ^ 1][i][1] = *reinterpret_cast<const half8*>(in_lo + bo + aoff[i]);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (!ILV) __builtin_amdgcn_sched_barrier(0);
             // the three partial products, outermost so that an accumulator is revisited only after
             // MTW*NTW other MFMAs (no back-to-back dependent MFMAs)
 #pragma unroll
@@ -181,6 +181,17 @@ struct ConvH {
                     for (int j = 0; j < NTW; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[RB][j][pr == 2 ? 1 : 0], x[RA][i][pr == 1 ? 1 : 0],
                                                                            acc[i][j], 0, 0, 0);
+            }
+            if (ILV) {  // the block's own LDS reads ride between its MFMAs instead of in front of them
+                constexpr int NP = 1 + (XLO ? 1 : 0) + ((WLO && !KSTACK) ? 1 : 0);
+                constexpr int NM = NP * MTW * NTW, ND = MTW * (XLO ? 2 : 1), NV = NTW * ((WLO && !KSTACK) ? 2 : 1);
+                __builtin_amdgcn_sched_group_barrier(0x020, NV, 0);
+#pragma unroll
+                for (int q = 0; q < ND; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NM - ND, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -448,7 +459,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
 
         // conv1: window (planes B) -> planes A
         if constexpr (FOLD)
-            ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, G::L1, G::WRS, 1, 8, 3, 1, 0, 0, true, false, true, K1>::run(
+            ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, G::L1, G::WRS, 1, 8, 3, 1, 0, 0, true, false, true, K1, true>::run(
                 b_hi, b_hi, reinterpret_cast<const half_t*>(W.c1f), EpiPlanesC1<G::RS, G::L1>{a_hi, a_lo, W.c1f_bias, W.c1f_corr},
                 [&](int k) __attribute__((always_inline)) { mk(2 + k); });
         else
@@ -468,7 +479,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         if (dbg && dbg_layer == 1 && s == 0) dump_planes<G::L1, 128, G::RS>(a_hi, a_lo, dbg);
 
         // conv2: planes A -> planes B
-        ConvH<NW, 128, 3, 128, G::L2, G::RS, 1, 8, 3, 1, 0, 0, !W16>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]),
+        ConvH<NW, 128, 3, 128, G::L2, G::RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]),
                                                            EpiPlanes<G::RS>{b_hi, b_lo, W.bias[1]}, [&](int k) __attribute__((always_inline)) { mk(6 + k); });
         mk(8);
         zero_rows_h<128>(b_hi, b_lo, 0, G::L2 + 1, G::RS);
@@ -477,7 +488,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         if (dbg && dbg_layer == 2 && s == 0) dump_planes<G::L2, 128, G::RS>(b_hi, b_lo, dbg);
 
         // conv3: planes B -> planes A
-        ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 4, 1, 0, 0, !W16>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
+        ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 4, 1, 0, 0, !W16, true, false, 0, true>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
                                                            EpiPlanes<G::RS>{a_hi, a_lo, W.bias[2]}, [&](int k) __attribute__((always_inline)) { mk(10 + k); });
         mk(12);
         zero_rows_h<128>(a_hi, a_lo, 0, G::L3 + 1, G::RS);
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
 
         // conv4: planes A -> act4[s] (fp32, hand-off to the tail kernel) on 6 waves (one 16-channel tile column
         // each, weights 3 k-blocks ahead); the other 2 build the next site's window in planes B meanwhile
-        ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 4, 1, 0, 0, !W16>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]),
+        ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 4, 1, 0, 0, !W16, true, false, 0, true>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]),
                                                             EpiGlobalF<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]}, [&](int k) __attribute__((always_inline)) { mk(14 + k); });
         mk(16);
         const int sn = s + gridDim.x;
