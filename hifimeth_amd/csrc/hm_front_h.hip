@@ -185,13 +185,14 @@ struct ConvH {
             if (ILV) {  // the block's own LDS reads ride between its MFMAs instead of in front of them
                 constexpr int NP = 1 + (XLO ? 1 : 0) + ((WLO && !KSTACK) ? 1 : 0);
                 constexpr int NM = NP * MTW * NTW, ND = MTW * (XLO ? 2 : 1), NV = NTW * ((WLO && !KSTACK) ? 2 : 1);
-                __builtin_amdgcn_sched_group_barrier(0x020, NV, 0);
 #pragma unroll
                 for (int q = 0; q < ND; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, NM - ND, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, NV, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NM - ND - 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
