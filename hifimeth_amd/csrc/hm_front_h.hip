@@ -69,7 +69,7 @@ __device__ __forceinline__ void split4(const f32x4& v, half4& hi, half4& lo) {
 // product per block covers both and only ceil(2*K1 / 4) blocks are needed (7 instead of 4 x 2 for K1 = 13).  KT_ is then
 // the number of tap slots (a multiple of 4) and the weights have no plane dimension.
 template <int NW_, int CIN_, int KT_, int COUT_, int LOUT_, int IRS_, int WM_, int WN_, int BR_ = 2, int S_ = 1,
-          int ISS_ = 0, int ROW0_ = 0, bool WLO = true, bool XLO = true, bool EDGE = false, int KSTACK = 0, bool ILV = false>
+          int ISS_ = 0, int ROW0_ = 0, bool WLO = true, bool XLO = true, bool EDGE = false, int KSTACK = 0, bool ILV = false, int LASTT = 0>
 struct ConvH {
     static constexpr int NW = NW_, CIN = CIN_, KT = KT_, COUT = COUT_, LOUT = LOUT_, IRS = IRS_, WM = WM_, WN = WN_, BR = BR_;
     static constexpr int S = S_, ISS = ISS_, ROW0 = ROW0_;
@@ -198,17 +198,35 @@ struct ConvH {
         };
         mark(0);
         constexpr int UN = BR % 2 == 0 ? BR : 2 * BR;
+        // with LASTT the final k-block is peeled: its MFMAs go tile by tile (all products of tile 0, then tile 1, ...) and no
+        // scheduling fence follows, so the epilogue of the first tiles can issue while the MFMAs of the last ones still run
+        constexpr int KBL = KB - LASTT;
         int kb = 0;
 #pragma nounroll
-        for (; kb + UN <= KB; kb += UN) {
+        for (; kb + UN <= KBL; kb += UN) {
             [&]<int... R>(std::integer_sequence<int, R...>) __attribute__((always_inline)) {
                 (block(std::integral_constant<int, R % BR>{}, std::integral_constant<int, R % 2>{}, kb + R), ...);
             }(std::make_integer_sequence<int, UN>{});
         }
         [&]<int... R>(std::integer_sequence<int, R...>) __attribute__((always_inline)) {
-            ((R < KB % UN ? block(std::integral_constant<int, R % BR>{}, std::integral_constant<int, R % 2>{}, KB - KB % UN + R)
-                          : (void)0), ...);
+            ((R < KBL % UN ? block(std::integral_constant<int, R % BR>{}, std::integral_constant<int, R % 2>{}, KBL - KBL % UN + R)
+                           : (void)0), ...);
         }(std::make_integer_sequence<int, UN>{});
+        if constexpr (LASTT > 0) {
+            static_assert(LASTT <= 2 && LASTT <= BR - 1, "the peeled blocks must all be resident in the rings");
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int b = KB - LASTT; b < KB; ++b)
+#pragma unroll
+                        for (int pr = 0; pr < 3; ++pr) {
+                            if ((pr == 1 && !XLO) || (pr == 2 && (!WLO || KSTACK))) continue;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[b % BR][j][pr == 2 ? 1 : 0], x[b % 2][i][pr == 1 ? 1 : 0],
+                                                                               acc[i][j], 0, 0, 0);
+                        }
+        }
         mark(1);
 
 #pragma unroll
@@ -480,7 +498,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         if (dbg && dbg_layer == 1 && s == 0) dump_planes<G::L1, 128, G::RS>(a_hi, a_lo, dbg);
 
         // conv2: planes A -> planes B
-        ConvH<NW, 128, 3, 128, G::L2, G::RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]),
+        ConvH<NW, 128, 3, 128, G::L2, G::RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 1>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]),
                                                            EpiPlanes<G::RS>{b_hi, b_lo, W.bias[1]}, [&](int k) __attribute__((always_inline)) { mk(6 + k); });
         mk(8);
         zero_rows_h<128>(b_hi, b_lo, 0, G::L2 + 1, G::RS);
@@ -489,7 +507,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         if (dbg && dbg_layer == 2 && s == 0) dump_planes<G::L2, 128, G::RS>(b_hi, b_lo, dbg);
 
         // conv3: planes B -> planes A
-        ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 4, 1, 0, 0, !W16, true, false, 0, true>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
+        ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 4, 1, 0, 0, !W16, true, false, 0, true, 1>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
                                                            EpiPlanes<G::RS>{a_hi, a_lo, W.bias[2]}, [&](int k) __attribute__((always_inline)) { mk(10 + k); });
         mk(12);
         zero_rows_h<128>(a_hi, a_lo, 0, G::L3 + 1, G::RS);
