@@ -23,13 +23,11 @@ typedef _Float16 half_t;
 
 typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
 
-// max(x, 0) as ONE v_max_f32: fmaxf() makes the compiler quiet a possible signalling NaN first (an extra
-// v_max_f32 x, x, x per value); MFMA results need no such canonicalisation.
-__device__ __forceinline__ float relu1(float x) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
+// max(x, 0) as ONE instruction (v_med3_f32 x, 0, +inf): fmaxf() makes the compiler quiet a possible signalling NaN first
+// (an extra v_max_f32 x, x, x per value).  A compiler builtin, NOT inline asm: x is an MFMA result, and the wait states an
+// MFMA result needs before a VALU read are only inserted for instructions the compiler can see -- an asm v_max_f32 placed
+// right behind the MFMAs of its tile read stale accumulators.
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
 
 // lo halves of two values: fp16(x - hi) with v_fma_mix{lo,hi}_f16 -- the f16 half is widened inside the instruction,
 // subtracted from the fp32 x exactly and the residual rounded once (2 instructions instead of 2 cvt + 2 sub + 1 cvt_pk)
@@ -498,7 +496,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         if (dbg && dbg_layer == 1 && s == 0) dump_planes<G::L1, 128, G::RS>(a_hi, a_lo, dbg);
 
         // conv2: planes A -> planes B
-        ConvH<NW, 128, 3, 128, G::L2, G::RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 0>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]),
+        ConvH<NW, 128, 3, 128, G::L2, G::RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 1>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]),
                                                            EpiPlanes<G::RS>{b_hi, b_lo, W.bias[1]}, [&](int k) __attribute__((always_inline)) { mk(6 + k); });
         mk(8);
         zero_rows_h<128>(b_hi, b_lo, 0, G::L2 + 1, G::RS);
@@ -507,7 +505,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         if (dbg && dbg_layer == 2 && s == 0) dump_planes<G::L2, 128, G::RS>(b_hi, b_lo, dbg);
 
         // conv3: planes B -> planes A
-        ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 4, 1, 0, 0, !W16, true, false, 0, true, 0>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
+        ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 4, 1, 0, 0, !W16, true, false, 0, true, 1>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
                                                            EpiPlanes<G::RS>{a_hi, a_lo, W.bias[2]}, [&](int k) __attribute__((always_inline)) { mk(10 + k); });
         mk(12);
         zero_rows_h<128>(a_hi, a_lo, 0, G::L3 + 1, G::RS);
