@@ -112,12 +112,23 @@ struct ConvH {
         };
 
         int aoff[MTW];
+        if constexpr (WM == 1 && S == 1) {
+            // one base register: tiles 0..MTW-2 are full, so their rows sit at compile-time strides from tile 0 (the LDS
+            // reads then carry the tile as an immediate offset); only the ragged last tile clamps its row
+            const int a0 = (2 * li + ROW0) * IRS + lk_off;
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            int m = (wm * MTW + i) * 16 + li;
+            for (int i = 0; i < MTW - 1; ++i) aoff[i] = a0 + i * (32 * IRS);
+            int m = (MTW - 1) * 16 + li;
             m = m < M ? m : M - 1;
-            const int site = S == 1 ? 0 : m / LOUT, p = S == 1 ? m : m - site * LOUT;
-            aoff[i] = site * ISS + (2 * p + ROW0) * IRS + lk_off;
+            aoff[MTW - 1] = (2 * m + ROW0) * IRS + lk_off;
+        } else {
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                int m = (wm * MTW + i) * 16 + li;
+                m = m < M ? m : M - 1;
+                const int site = S == 1 ? 0 : m / LOUT, p = S == 1 ? m : m - site * LOUT;
+                aoff[i] = site * ISS + (2 * p + ROW0) * IRS + lk_off;
+            }
         }
         f32x4 acc[MTW][NTW];
 #pragma unroll
