@@ -7,6 +7,12 @@
 // layer are split again when they are written to LDS.  Same algorithm and layouts as hm_kernels.hip otherwise:
 // one site per workgroup pass, activations channels-last in LDS (now as an fp16 hi plane and an fp16 lo plane,
 // 4 bytes per element as before), weights as the MFMA A operand so that a lane owns 4 consecutive channels.
+// conv1 on the staged-read path is the exception: bn0 is folded into its weights (hm_weights.cpp), which makes its
+// operand -- the one-hot base and the decoded frame counts / 32 -- EXACT in fp16: no lo plane, and the weights' hi and
+// lo halves ride along K as extra "taps", so one MFMA product per k-block does the whole job (ConvH<..., KSTACK>).
+// Scheduling notes that were each worth 1-3 % in same-box A/Bs: a k-block's LDS reads are interleaved with its first
+// MFMAs (ILV), the last k-block of conv2 / conv3 is issued tile by tile so the epilogue starts under it (LASTT), and no
+// inline asm may read an MFMA result (the compiler only inserts the required wait states for instructions it can see).
 // Reference for what is computed: training/model_cnn.py:8-85 / models/*.onnx (mod_main.cpp:32-98).
 #include <type_traits>
 #include <utility>
