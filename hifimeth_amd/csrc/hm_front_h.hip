@@ -532,7 +532,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
 
         // conv4: planes A -> act4[s] (fp32, hand-off to the tail kernel) on 6 waves (one 16-channel tile column
         // each, weights 3 k-blocks ahead); the other 2 build the next site's window in planes B meanwhile
-        ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 4, 1, 0, 0, !W16, true, false, 0, true>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]),
+        ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 4, 1, 0, 0, !W16, true, false, 0, true, 1>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]),
                                                             EpiGlobalF<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]}, [&](int k) __attribute__((always_inline)) { mk(14 + k); });
         mk(16);
         const int sn = s + gridDim.x;
