@@ -522,7 +522,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         if (dbg && dbg_layer == 2 && s == 0) dump_planes<G::L2, 128, G::RS>(b_hi, b_lo, dbg);
 
         // conv3: planes B -> planes A
-        ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 4, 1, 0, 0, !W16, true, false, 0, true, 1>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
+        ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 1>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
                                                            EpiPlanes<G::RS>{a_hi, a_lo, W.bias[2]}, [&](int k) __attribute__((always_inline)) { mk(10 + k); });
         mk(12);
         zero_rows_h<128>(a_hi, a_lo, 0, G::L3 + 1, G::RS);
