@@ -5,6 +5,7 @@
 // The host parses the BAM and the MM/ML lists (parallel over the reads of a batch); alignment projection,
 // histograms and per-locus counting run on the GPU through the hm_pileup_* C ABI.  No temporary file is written:
 // the projected calls stay in HBM until the thresholds are known.
+#include <strings.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -152,6 +153,127 @@ int cmd_corr(int argc, char** argv) {
     const double corr = (vx == 0 || vy == 0) ? 0.0 : cov / std::sqrt(vx * vy);
     fprintf(stdout, "Intersect loci: %zu\n", n);
     fprintf(stderr, "correlation: %g\n", corr);
+    return 0;
+}
+
+// cov2bed REF.fa CONTEXT bismark.cov out.bed : 1-based Bismark coverage rows -> 0-based BED rows with a motif column
+// (src/app/hifimeth/cov_to_bed.cpp).  Each input row "chr pos pos freq pcov ncov" is looked up on the reference and
+// follows one rule of the table below: rows on a 'C' start a locus, rows on a 'G' either fold into the locus of the
+// palindromic partner on the forward strand (CpG: one base left; CAG/CTG: two bases left) or stay where they are
+// (CCG's partner CGG, every CHH motif, which is always named by its forward-strand spelling).  A chromosome's loci are
+// written when the input moves on to another chromosome, as the reference does.  Neighbours outside the chromosome
+// never match (the reference reads into the adjacent sequence there).  Host only, no GPU.
+int cmd_cov2bed(int argc, char** argv) {
+    if (argc != 6) {
+        fprintf(stderr, "USAGE:\n%s %s reference context bismark-call bed\n", argv[0], argv[1]);
+        return 1;
+    }
+    const std::string context = argv[3];
+    int ctx = -1;
+    if (context.size() == 3) {
+        if (strcasecmp(context.c_str(), "CpG") == 0) ctx = 0;
+        else if (strcasecmp(context.c_str(), "CHG") == 0) ctx = 1;
+        else if (strcasecmp(context.c_str(), "CHH") == 0) ctx = 2;
+    }
+    if (ctx < 0) {
+        fprintf(stderr, "Illegal 5mc context: %s\nPlausible contexts: CpG, CHG, CHH\n", context.c_str());
+        return 1;
+    }
+    Fasta fa;
+    std::string err;
+    if (!load_fasta(argv[2], fa, err)) { fprintf(stderr, "ERROR: %s\n", err.c_str()); return EXIT_FAILURE; }
+    std::vector<int64_t> start(fa.names.size() + 1, 0);
+    for (size_t s = 0; s < fa.names.size(); ++s) start[s + 1] = start[s] + fa.length[s];
+
+    // one rule: the row's own base, the 3-mer window it is matched against (offset of the window's first base relative
+    // to the row), where the counts go (relative to the row), whether they replace or add, and the motif written
+    struct Rule { char base; int win; const char* kmer; int dst; bool add; const char* motif; };
+    static const Rule cpg[] = {{'C', 0, "CG", 0, false, "CG"}, {'G', -1, "CG", -1, true, "CG"}};
+    static const Rule chg[] = {{'C', 0, "CCG", 0, false, "CCG"}, {'G', -2, "CGG", 0, false, "CCG"},
+                               {'C', 0, "CAG", 0, false, "CAG"}, {'G', -2, "CAG", -2, true, "CAG"},
+                               {'C', 0, "CTG", 0, false, "CTG"}, {'G', -2, "CTG", -2, true, "CTG"}};
+    static const Rule chh[] = {{'C', 0, "CAA", 0, false, "CAA"}, {'C', 0, "CCA", 0, false, "CCA"}, {'C', 0, "CTA", 0, false, "CTA"},
+                               {'C', 0, "CAC", 0, false, "CAC"}, {'C', 0, "CCC", 0, false, "CCC"}, {'C', 0, "CTC", 0, false, "CTC"},
+                               {'C', 0, "CAT", 0, false, "CAT"}, {'C', 0, "CCT", 0, false, "CCT"}, {'C', 0, "CTT", 0, false, "CTT"},
+                               {'G', -2, "TTG", 0, false, "CAA"}, {'G', -2, "TGG", 0, false, "CCA"}, {'G', -2, "TAG", 0, false, "CTA"},
+                               {'G', -2, "GTG", 0, false, "CAC"}, {'G', -2, "GGG", 0, false, "CCC"}, {'G', -2, "GAG", 0, false, "CTC"},
+                               {'G', -2, "ATG", 0, false, "CAT"}, {'G', -2, "AGG", 0, false, "CCT"}, {'G', -2, "AAG", 0, false, "CTT"}};
+    const Rule* rules = ctx == 0 ? cpg : ctx == 1 ? chg : chh;
+    const int n_rules = ctx == 0 ? 2 : ctx == 1 ? 6 : 18;
+
+    struct Locus { int pcov, ncov; const char* motif; };
+    std::vector<Locus> loci;
+    FILE* out = fopen(argv[5], "w");
+    if (!out) { fprintf(stderr, "ERROR: cannot open %s for writing\n", argv[5]); return EXIT_FAILURE; }
+    gzFile in = gzopen(argv[4], "rb");
+    if (!in) { fprintf(stderr, "ERROR: cannot open %s\n", argv[4]); fclose(out); return EXIT_FAILURE; }
+    int cur = -1;
+    bool bad = false;
+    auto dump = [&]() {
+        if (cur < 0) return;
+        std::string text;
+        char row[256];
+        for (size_t i = 0; i < loci.size(); ++i) {
+            const Locus& l = loci[i];
+            if (!l.motif) continue;
+            const int cov = l.pcov + l.ncov;
+            if (cov <= 0) { fprintf(stderr, "ERROR: locus %s:%zu has no coverage\n", fa.names[cur].c_str(), i); bad = true; return; }
+            const int len = snprintf(row, sizeof row, "\t%zu\t%zu\t%g\t%d\t%d\t%s\n", i, i + 1, 100.0 * l.pcov / cov, l.pcov, l.ncov, l.motif);
+            text += fa.names[cur];
+            text.append(row, (size_t)len);
+        }
+        fwrite(text.data(), 1, text.size(), out);
+    };
+    size_t fs = 0, rs = 0;
+    static char line[1 << 16];
+    std::string last_name;
+    while (!bad && gzgets(in, line, sizeof line)) {
+        size_t ll = strlen(line);
+        while (ll && (line[ll - 1] == '\n' || line[ll - 1] == '\r')) line[--ll] = 0;
+        char* col[6];
+        int nc = 0;
+        char* p = line;
+        col[nc++] = p;
+        for (; *p && nc < 6; ++p)
+            if (*p == '\t') { *p = 0; col[nc++] = p + 1; }
+        if (nc < 6) { fprintf(stderr, "ERROR: corrupted bismark record %s\n", line); bad = true; break; }
+        if (cur < 0 || last_name != col[0]) {
+            const int sid = fa.find(col[0]);
+            if (sid < 0) { fprintf(stderr, "ERROR: sequence %s is not in %s\n", col[0], argv[2]); bad = true; break; }
+            dump();
+            if (bad) break;
+            cur = sid;
+            last_name = col[0];
+            loci.assign((size_t)fa.length[sid], Locus{0, 0, nullptr});
+        }
+        const int64_t pos1 = atoll(col[1]);
+        if (atoll(col[2]) != pos1) { fprintf(stderr, "ERROR: start and end differ: %s:%s-%s\n", col[0], col[1], col[2]); bad = true; break; }
+        const int pcov = atoi(col[4]), ncov = atoi(col[5]);
+        const int64_t len = fa.length[cur], soff = pos1 - 1;
+        if (soff < 0 || soff >= len) { fprintf(stderr, "ERROR: position %s is outside %s\n", col[1], col[0]); bad = true; break; }
+        const char* chr = fa.bases.data() + start[cur];
+        for (int r = 0; r < n_rules; ++r) {
+            const Rule& R = rules[r];
+            if (chr[soff] != R.base) continue;
+            const int k = (int)strlen(R.kmer);
+            const int64_t w = soff + R.win;
+            if (w < 0 || w + k > len || strncmp(chr + w, R.kmer, (size_t)k) != 0) continue;
+            Locus& l = loci[(size_t)(soff + R.dst)];
+            if (R.add) {
+                l.pcov += pcov;
+                l.ncov += ncov;
+                if (!l.motif) l.motif = R.motif;
+            } else {
+                l = Locus{pcov, ncov, R.motif};
+            }
+            ++(R.base == 'C' ? fs : rs);
+        }
+    }
+    gzclose(in);
+    if (!bad) dump();
+    fclose(out);
+    if (bad) return EXIT_FAILURE;
+    fprintf(stderr, "forward-strand-sites: %zu, reverse-strand-sites: %zu\n", fs, rs);
     return 0;
 }
 

@@ -6,6 +6,7 @@ Pin status: `cigar_to_alignment`, `map_info` and `chh_mapped_samples` are checke
 (oracle/ref_build builds BamMapInfo::init + 5mc_motif_finder.cpp into oracle/_ref/ref_align; fixtures in
 tests/golden/align.json).  The MM/ML parser (bam_mod_parser.cpp) and the record/count/BED stages of pileup.cpp call
 htslib functions whose library is not in this image, so those stages are a restatement by reading: PARITY UNPINNED.
+`cov_to_bed` is pinned against the reference's whole `cov2bed` subcommand (oracle/_ref/ref_tools, tests/golden/helpers.json).
 
 Where the reference's output depends on thread timing (two motif classes landing on one locus, see `count`), the
 restatement fixes the order to "BAM order, classes CpG < CHG < CHH within a read", i.e. what one reference thread
@@ -284,6 +285,65 @@ def pileup(records, chrs, min_mapq=0, min_pi=0.0, thresholds=None):
         bed[("CpG", "CHG", "CHH")[motif]].append("%s\t%d\t%d\t%g\t%d\t%d\n" % (chrs[sid][0], soff, soff + 1,
                                                                                 100.0 * p / (p + n), p, n))
     return dict(bins=bins, thresholds=thr, records=allrec, loci=loci, bed={k: "".join(v) for k, v in bed.items()})
+
+
+# ---- helpers: cov2bed (src/app/hifimeth/cov_to_bed.cpp) ---------------------------------------------------------
+def cov_to_bed(chrs, context, cov_text):
+    """`hifimeth cov2bed reference context bismark-call bed` -> (bed text, forward sites, reverse sites).
+    Pinned against the reference's own subcommand (oracle/_ref/ref_tools; fixtures in tests/golden/helpers.json).
+    CpG  : cov_to_bed.cpp:36-142   C+G starts a locus, a row on the G of CG adds to the locus one base left
+    CHG  : cov_to_bed.cpp:144-294  CCG / CAG / CTG start a locus; a G closing CGG stays in place (named CCG); a G
+                                   closing CAG / CTG adds to the locus two bases left
+    CHH  : cov_to_bed.cpp:296-394  9 forward motifs on C; a G closing one of the 9 reverse motifs stays in place and
+                                   is named by the forward spelling of the same index (5mc_context.cpp:9-10)
+    A chromosome's loci are written out when the input moves to another chromosome (:59-67)."""
+    names = [n for n, _ in chrs]
+    ctx = context.lower()
+    out, fs, rs = [], 0, 0
+    cur, loci = None, None
+
+    def dump():
+        if cur is None:
+            return
+        for i in sorted(loci):
+            pc, nc, motif = loci[i]
+            assert pc + nc > 0
+            out.append("%s\t%d\t%d\t%g\t%d\t%d\t%s\n" % (names[cur], i, i + 1, 100.0 * pc / (pc + nc), pc, nc, motif))
+
+    for line in cov_text.split("\n"):
+        if not line:
+            continue
+        col = line.split("\t")
+        sid = names.index(col[0])
+        if sid != cur:
+            dump()
+            cur, loci = sid, {}
+        sq = chrs[sid][1]
+        soff, pc, nc = int(col[1]) - 1, int(col[4]), int(col[5])
+        assert int(col[2]) - 1 == soff
+        b = sq[soff]
+        nxt, prv = sq[soff:soff + 3], sq[max(soff - 2, 0):soff + 1]
+        if ctx == "cpg":
+            if b == "C" and nxt[:2] == "CG":
+                loci[soff] = [pc, nc, "CG"]; fs += 1
+            if b == "G" and prv[-2:] == "CG":
+                e = loci.setdefault(soff - 1, [0, 0, "CG"]); e[0] += pc; e[1] += nc; e[2] = "CG"; rs += 1
+        elif ctx == "chg":
+            if b == "C" and nxt in FWD_CHG:
+                loci[soff] = [pc, nc, nxt]; fs += 1
+            if b == "G" and prv == "CGG":
+                loci[soff] = [pc, nc, "CCG"]; rs += 1
+            if b == "G" and prv in ("CAG", "CTG"):
+                e = loci.setdefault(soff - 2, [0, 0, prv]); e[0] += pc; e[1] += nc; rs += 1
+        elif ctx == "chh":
+            if b == "C" and nxt in FWD_CHH:
+                loci[soff] = [pc, nc, nxt]; fs += 1
+            elif b == "G" and prv in REV_CHH:
+                loci[soff] = [pc, nc, "".join(_COMP[c] for c in reversed(prv))]; rs += 1   # kRev[i] = revcomp(kFwd[i])
+        else:
+            raise ValueError("Illegal 5mc context: " + context)
+    dump()
+    return "".join(out), fs, rs
 
 
 # ---- the reference's own alignment code (oracle/_ref/ref_align), used to pin the functions above ---------------

@@ -223,14 +223,85 @@ def make_align():
           f"{sum(len(d['chh']) for d in out if d)} CHH samples")
 
 
+def make_helpers():
+    """helpers.json: the reference's own `cov2bed` and `corr` subcommands (src/app/hifimeth/cov_to_bed.cpp,
+    pileup_correlation.cpp), built by oracle/ref_build into oracle/_ref/ref_tools, run on a synthetic genome with
+    Bismark-style coverage rows on every C and G (both strands, rows on the partner strand only, rows in non-motif
+    positions, a chromosome that is visited twice) and on two BED files with partially shared loci."""
+    import subprocess
+    from hifimeth_amd.synth import synth_genome
+    tools = os.path.join(ROOT, "oracle", "_ref", "ref_tools")
+    genome = synth_genome(n_chr=3, length=1200, seed=41)
+    rng = np.random.default_rng(43)
+    fa = "/tmp/_golden_helpers.fa"
+    with open(fa, "w") as f:
+        for n, sq in genome:
+            f.write(f">{n}\n")
+            for i in range(0, len(sq), 60):
+                f.write(sq[i:i + 60] + "\n")
+    out = dict(genome=genome, cov2bed={}, corr=[])
+    order = [0, 1, 2, 0]                                   # chromosome 0 comes back after the others
+    for ctx in ("CpG", "CHG", "CHH"):
+        rows = []
+        for visit, ci in enumerate(order):
+            name, sq = genome[ci]
+            lo, hi = (0, len(sq) // 2) if (ci == 0 and visit == 0) else (len(sq) // 2, len(sq)) if ci == 0 else (0, len(sq))
+            for i in range(max(lo, 3), min(hi, len(sq) - 3)):   # the reference reads neighbours without bounds checks
+                if sq[i] in "CG" and rng.random() < 0.8 or rng.random() < 0.02:
+                    pc, nc = int(rng.integers(0, 30)), int(rng.integers(0, 30))
+                    if pc + nc == 0:
+                        pc = 1
+                    rows.append(f"{name}\t{i + 1}\t{i + 1}\t{100.0 * pc / (pc + nc):.6f}\t{pc}\t{nc}")
+        cov, bed = f"/tmp/_golden_{ctx}.cov", f"/tmp/_golden_{ctx}.bed"
+        open(cov, "w").write("\n".join(rows) + "\n")
+        r = subprocess.run([tools, "cov2bed", fa, ctx.lower() if ctx == "CHG" else ctx, cov, bed], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        out["cov2bed"][ctx] = dict(cov=open(cov).read(), bed=open(bed).read(),
+                                   stderr=[l for l in r.stderr.split("\n") if l.startswith("forward-strand-sites")][0])
+        print(f"cov2bed {ctx}: {len(rows)} rows -> {out['cov2bed'][ctx]['bed'].count(chr(10))} loci; {out['cov2bed'][ctx]['stderr']}")
+        os.remove(cov)
+    # corr: the CpG BED above against a perturbed copy (some loci dropped, counts jittered, chromosome order swapped)
+    a = out["cov2bed"]["CpG"]["bed"]
+    lines = [l.split("\t") for l in a.strip().split("\n")]
+    pert = []
+    for l in lines:
+        if rng.random() < 0.15:
+            continue
+        pc = max(0, int(l[4]) + int(rng.integers(-3, 4)))
+        nc = max(0, int(l[5]) + int(rng.integers(-3, 4)))
+        if pc + nc == 0:
+            nc = 1
+        pert.append((l[0], int(l[1]), pc, nc))
+    pert.sort(key=lambda t: (-[n for n, _ in genome].index(t[0]), t[1]))
+    b = "".join(f"{c}\t{s}\t{s + 1}\t{100.0 * pc / (pc + nc):g}\t{pc}\t{nc}\tCG\n" for c, s, pc, nc in pert)
+    pa, pb = "/tmp/_golden_a.bed", "/tmp/_golden_b.bed"
+    open(pa, "w").write(a)
+    open(pb, "w").write(b)
+    for args in ([], ["-c", "1"], ["-c", "20"], ["-c", "200"]):
+        r = subprocess.run([tools, "corr"] + args + [pa, pb], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        corr = [l for l in r.stderr.split("\n") if l.startswith("correlation:")]
+        out["corr"].append(dict(args=args, stdout=r.stdout, correlation=corr[0] if corr else None,
+                                skipped="Skip computation" in r.stderr))
+        print("corr", args, r.stdout.strip(), corr)
+    out["corr_beds"] = [a, b]
+    json.dump(out, open(os.path.join(GOLD, "helpers.json"), "w"))
+    for f_ in (fa, pa, pb, "/tmp/_golden_CpG.bed", "/tmp/_golden_CHG.bed", "/tmp/_golden_CHH.bed"):
+        os.remove(f_)
+
+
 if __name__ == "__main__":
     if not O.ref_scan_available():
         raise SystemExit("build oracle/_ref first: make -C oracle")
     if len(sys.argv) > 2 and sys.argv[2] == "align":      # only the pileup fixtures
         make_align()
         raise SystemExit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "helpers":    # only the cov2bed / corr fixtures
+        make_helpers()
+        raise SystemExit(0)
     make_scan()
     w = make_windows()
     make_cnn(w)
     make_config_goldens()
     make_align()
+    make_helpers()
