@@ -413,6 +413,7 @@ int cmd_pileup(int argc, char** argv);   // hifimeth_pileup.cpp
 int cmd_fastats(int argc, char** argv);  // hifimeth_pileup.cpp
 int cmd_corr(int argc, char** argv);     // hifimeth_pileup.cpp
 int cmd_cov2bed(int argc, char** argv);  // hifimeth_pileup.cpp
+int cmd_sample(int argc, char** argv);   // hifimeth_pileup.cpp
 
 int main(int argc, char** argv) {
     if (argc < 2) { usage(); return EXIT_FAILURE; }
@@ -425,6 +426,7 @@ int main(int argc, char** argv) {
     if (cmd == "fastats") return cmd_fastats(argc, argv);
     if (cmd == "corr") return cmd_corr(argc, argv);
     if (cmd == "cov2bed") return cmd_cov2bed(argc, argv);
+    if (cmd == "sample") return cmd_sample(argc, argv);
     usage();
     return EXIT_FAILURE;
 }

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <random>
 #include <string>
 #include <thread>
 #include <vector>
@@ -274,6 +275,103 @@ int cmd_cov2bed(int argc, char** argv) {
     fclose(out);
     if (bad) return EXIT_FAILURE;
     fprintf(stderr, "forward-strand-sites: %zu, reverse-strand-sites: %zu\n", fs, rs);
+    return 0;
+}
+
+// sample [-s seed] REF.fa in.bam COVERAGE out.bam : random subset of the usable reads of an (unaligned) HiFi BAM adding
+// up to COVERAGE x the reference size (src/app/hifimeth/subsample_bam.cpp).  A read is usable when it has >= 5000
+// bases and all four kinetics arrays (:18-28); usable reads are shuffled, taken until the base target is reached (the
+// read that crosses it included, :97-103) and written in input order (:105-117).  The reference seeds its shuffle from
+// std::random_device, so which reads come out is not reproducible there either; `-s` (ours) fixes the seed for tests.
+namespace {
+std::string human_size(uint64_t bytes) {  // bytes_to_datasize (src/corelib/hbn_aux.cpp:447-490): 1024-based, <= 3 digits
+    static const char* unit[] = {"B", "KB", "MB", "GB", "TB", "PB", "EB"};
+    if (bytes == 0) return "0B";
+    double v = (double)bytes;
+    int u = 0;
+    while (v >= 1024.0 && u < 6) { v /= 1024.0; ++u; }
+    char buf[64];
+    if (u == 0 || v >= 100) snprintf(buf, sizeof buf, "%llu", (unsigned long long)std::llround(v));
+    else snprintf(buf, sizeof buf, v >= 10 ? "%.1f" : "%.2f", v);
+    std::string r = buf;
+    if (r.find('.') != std::string::npos) {
+        r.erase(r.find_last_not_of('0') + 1);
+        if (r.back() == '.') r.pop_back();
+    }
+    return r + unit[u];
+}
+}  // namespace
+
+int cmd_sample(int argc, char** argv) {
+    int a = 2;
+    bool seeded = false;
+    uint64_t seed = 0;
+    if (argc >= 4 && std::string(argv[2]) == "-s") { seeded = true; seed = strtoull(argv[3], nullptr, 10); a = 4; }
+    if (argc - a != 4) {
+        fprintf(stderr, "USAGE:\n  %s %s [-s seed] reference input-bam coverage output-bam\n", argv[0], argv[1]);
+        return 1;
+    }
+    const char* ref_path = argv[a];
+    const char* in_path = argv[a + 1];
+    const int cov = atoi(argv[a + 2]);
+    const char* out_path = argv[a + 3];
+    Fasta fa;
+    std::string err;
+    if (!load_fasta(ref_path, fa, err)) { fprintf(stderr, "ERROR: %s\n", err.c_str()); return EXIT_FAILURE; }
+    const uint64_t dbsize = fa.bases.size(), target = dbsize * (uint64_t)std::max(cov, 0);
+
+    struct Info { uint32_t id; int32_t length; bool valid, selected; };
+    std::vector<Info> list;
+    uint64_t total = 0;
+    {
+        BgzfReader in(in_path, 8);
+        BamHeader h;
+        if (!in.ok() || !read_header(in, h, err)) { fprintf(stderr, "ERROR: %s: %s\n", in_path, err.empty() ? "cannot open" : err.c_str()); return EXIT_FAILURE; }
+        BamRecord r;
+        while (read_record(in, r, err)) {
+            Info f{(uint32_t)list.size(), r.l_qseq(), false, false};
+            if (f.length >= 5000) {
+                const KineticsView kv = kinetics_of(r);
+                f.valid = kv.arr[0] && kv.arr[1] && kv.arr[2] && kv.arr[3];
+            }
+            if (f.valid) total += (uint64_t)f.length;
+            list.push_back(f);
+        }
+        if (!err.empty()) { fprintf(stderr, "ERROR: %s: %s\n", in_path, err.c_str()); return EXIT_FAILURE; }
+    }
+    fprintf(stderr, "DB size: %s\ncoverage: %d, target size: %s\nBAM size: %s\n", human_size(dbsize).c_str(), cov,
+            human_size(target).c_str(), human_size(total).c_str());
+    std::mt19937 gen(seeded ? (uint32_t)seed : std::random_device{}());
+    std::shuffle(list.begin(), list.end(), gen);
+    uint64_t picked = 0;
+    for (Info& f : list) {
+        if (!f.valid) continue;
+        picked += (uint64_t)f.length;
+        f.selected = true;
+        if (picked >= target) break;
+    }
+    std::sort(list.begin(), list.end(), [](const Info& x, const Info& y) { return x.id < y.id; });
+
+    BgzfReader in(in_path, 8);
+    BamHeader h;
+    if (!in.ok() || !read_header(in, h, err)) { fprintf(stderr, "ERROR: %s: %s\n", in_path, err.c_str()); return EXIT_FAILURE; }
+    BgzfWriter out(out_path, 8, 6);
+    if (!out.ok()) { fprintf(stderr, "ERROR: cannot open %s for writing\n", out_path); return EXIT_FAILURE; }
+    write_header(out, h);
+    BamRecord r;
+    size_t id = 0;
+    int reads = 0;
+    uint64_t bases = 0;
+    while (read_record(in, r, err)) {
+        if (id >= list.size()) { fprintf(stderr, "ERROR: %s changed between the two passes\n", in_path); return EXIT_FAILURE; }
+        const Info& f = list[id++];
+        if (!f.valid || !f.selected) continue;
+        write_record(out, r);
+        ++reads;
+        bases += (uint64_t)f.length;
+    }
+    if (!err.empty() || !out.close()) { fprintf(stderr, "ERROR: %s\n", err.empty() ? "write failed" : err.c_str()); return EXIT_FAILURE; }
+    fprintf(stderr, "Target: %s\nExtracted reads: %d (%s)\n", human_size(target).c_str(), reads, human_size(bases).c_str());
     return 0;
 }
 

@@ -235,3 +235,42 @@ def test_cli_survives_corrupted_records(tmp_path):
         for cmd in (["modstats", mut], ["bamcopy", mut, str(tmp_path / "o.bam")]):
             r = subprocess.run([CLI] + cmd, capture_output=True, timeout=60)
             assert r.returncode in (0, 1), (cmd[0], r.returncode, r.stderr[-300:])
+
+
+def test_cli_sample_properties(tmp_path):
+    """hifimeth-hip sample = src/app/hifimeth/subsample_bam.cpp.  The reference shuffles with a random_device seed, so
+    the checks are its invariants: only reads with >= 5000 bases and all four kinetics arrays come out, in input
+    order, byte-identical; the base total reaches coverage x reference size, and dropping the last pick would not."""
+    if not os.path.exists(CLI):
+        pytest.skip("CLI not built")
+    reads = synth_reads(60, seed=5, median_len=7000, min_len=1000, max_len=12000, frac_missing=0.1, frac_short=0.05)
+    src, fa = str(tmp_path / "in.bam"), str(tmp_path / "ref.fa")
+    bamutil.reads_to_bam(src, reads)
+    bamutil.write_fasta(fa, [("chr1", "ACGT" * 5000), ("chr2", "TTGCA" * 2000)])     # 30 000 bases
+    usable = {r.name: r.l_qseq for r in reads
+              if r.l_qseq >= 5000 and all(getattr(r, t) is not None and len(getattr(r, t)) == r.l_qseq for t in ("fi", "fp", "ri", "rp"))}
+    assert 10 < len(usable) < len(reads)
+    _, inp = bamutil.read_bam(src)
+    raw = {d["name"]: d["raw"] for d in inp}
+    order = [d["name"] for d in inp]
+    picks = []
+    for seed in (1, 2):
+        dst = str(tmp_path / f"out{seed}.bam")
+        r = subprocess.run([CLI, "sample", "-s", str(seed), fa, src, "3", dst], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "DB size: 29.3KB" in r.stderr and "target size: 87.9KB" in r.stderr
+        hdr, out = bamutil.read_bam(dst)
+        names = [d["name"] for d in out]
+        assert all(n in usable for n in names)
+        assert names == [n for n in order if n in set(names)]                  # input order kept
+        assert all(d["raw"] == raw[d["name"]] for d in out)                    # records untouched
+        total = sum(usable[n] for n in names)
+        assert total >= 90_000 and total - min(usable[n] for n in names) < 90_000 + max(usable.values())
+        assert f"Extracted reads: {len(names)} " in r.stderr
+        picks.append(tuple(names))
+    assert picks[0] != picks[1]                                                # the seed changes the draw
+    # a target beyond the file: every usable read, nothing else
+    dst = str(tmp_path / "all.bam")
+    assert subprocess.run([CLI, "sample", fa, src, "1000", dst], capture_output=True).returncode == 0
+    assert [d["name"] for d in bamutil.read_bam(dst)[1]] == [n for n in order if n in usable]
+    assert subprocess.run([CLI, "sample", fa, src, "3"], capture_output=True).returncode == 1
