@@ -141,7 +141,9 @@ def main():
     rank, local_rank, world = hmdist.env_world()
     # HM_DIST_BACKEND=gloo lets the multi-rank path be rehearsed on a box with fewer GPUs than ranks
     backend = os.environ.get("HM_DIST_BACKEND", "nccl")
-    dist = hmdist.init_process_group(backend) if world > 1 else None
+    # HM_BENCH_FORCE_DIST=1 builds a world of one, so that the RCCL barrier / reductions run on a one-GPU box too
+    force = os.environ.get("HM_BENCH_FORCE_DIST", "0") == "1"
+    dist = hmdist.init_process_group(backend, force=force) if (world > 1 or force) else None
     on_gpu_collectives = dist is not None and backend == "nccl"
 
     reads = synth_reads(args.reads, seed=20250220 + rank, gc=0.36)

@@ -1,0 +1,74 @@
+"""bench.py's contract, run as the driver runs it (one JSON line on stdout), on small batches."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+BENCH = os.path.join(ROOT, "bench.py")
+SMALL = ["--steps", "2", "--warmup", "1", "--reads", "12"]
+
+
+def _line(cmd, env=None, timeout=600):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, env=e, cwd=ROOT, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_common(d, n_gpus):
+    assert d["metric"] == "cytosine sites/sec (CpG+CHG+CHH)" and d["unit"] == "sites/s"
+    assert d["n_gpus"] == n_gpus and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and d["dtype"] == "f16x3+f32acc"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - n_gpus * d["config"]["sites_per_gpu_step"] * 2 / (d["ms_per_step"] * 2e-3)) < 0.35 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1 and "traffic" in rf
+
+
+def test_bench_line_single_gpu_with_cpu_baseline():
+    d = _line([sys.executable, BENCH] + SMALL)
+    _check_common(d, 1)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "sites/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert d["parity"]["max_abs_dp_vs_oracle"] <= d["parity"]["tolerance"] == 1e-4
+    assert d["parity"]["sites_checked"] > 10000
+
+
+def test_bench_rccl_world_of_one():
+    """the barrier and the two reductions of the multi-GPU path on RCCL, with one rank"""
+    port = _free_port()
+    d = _line([sys.executable, BENCH, "--no-cpu-baseline"] + SMALL,
+              env={"HM_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0",
+                   "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    _check_common(d, 1)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_two_ranks_launched_like_the_driver():
+    """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`: both ranks share the one card of this box (gloo for
+    the reductions, since RCCL refuses two ranks on one device); rank 0 prints the whole-job line"""
+    one = _line([sys.executable, BENCH, "--no-cpu-baseline"] + SMALL)
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), BENCH, "--gpus", "2"] + SMALL, env={"HM_DIST_BACKEND": "gloo"})
+    _check_common(d, 2)
+    assert "cpu_baseline" not in d
+    # two different read sets (seed + rank): about twice the sites of one rank
+    job_sites = d["value"] * d["ms_per_step"] * 1e-3
+    assert 1.5 < job_sites / one["config"]["sites_per_gpu_step"] < 2.5 and job_sites != 2 * one["config"]["sites_per_gpu_step"]
