@@ -90,6 +90,7 @@ def lib():
         "hm_pileup_num_records": (i64, [vp]),
         "hm_pileup_histograms": (C.c_int, [vp, vp]),
         "hm_pileup_fetch_records": (i64, [vp, vp, vp, vp, vp, i64]),
+        "hm_pileup_label_histograms": (C.c_int, [vp, vp, i64, vp]),
         "hm_pileup_count": (C.c_int, [vp, vp]),
         "hm_pileup_fetch_loci": (i64, [vp, vp, vp, vp, i64, i64, i64, vp, i64]),
     }

@@ -414,6 +414,7 @@ int cmd_fastats(int argc, char** argv);  // hifimeth_pileup.cpp
 int cmd_corr(int argc, char** argv);     // hifimeth_pileup.cpp
 int cmd_cov2bed(int argc, char** argv);  // hifimeth_pileup.cpp
 int cmd_sample(int argc, char** argv);   // hifimeth_pileup.cpp
+int cmd_eval(int argc, char** argv);     // hifimeth_pileup.cpp
 
 int main(int argc, char** argv) {
     if (argc < 2) { usage(); return EXIT_FAILURE; }
@@ -427,6 +428,7 @@ int main(int argc, char** argv) {
     if (cmd == "corr") return cmd_corr(argc, argv);
     if (cmd == "cov2bed") return cmd_cov2bed(argc, argv);
     if (cmd == "sample") return cmd_sample(argc, argv);
+    if (cmd == "eval") return cmd_eval(argc, argv);
     usage();
     return EXIT_FAILURE;
 }

@@ -18,12 +18,17 @@
 #include <random>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/hifimeth_hip.h"
 #include "hm_bam.h"
 
 using namespace hmbam;
+
+namespace {
+void report_thresholds(const uint64_t* bins, uint8_t thr[3]);
+}  // namespace
 
 namespace {
 
@@ -375,6 +380,223 @@ int cmd_sample(int argc, char** argv) {
     return 0;
 }
 
+// eval [-s seed] [-d DUMP.json] [-g device] REF.fa bismark.bed mod.bam PREFIX : read-level benchmark samples
+// (src/app/hifimeth/eval.cpp).  Truth labels come from a 0-based Bismark BED (rows with >= 10 reads: all unmethylated -> 0,
+// all methylated -> 1, :103-112); every 5mC call of a mapped read that projects onto a labelled locus -- the same
+// CpG / CHG / CHH walks as `pileup` (:503-560), here on the GPU through the pileup engine -- becomes one (label,
+// probability) sample.  Per context: CHH negatives are thinned to one in ten (:556), small sample sets are replicated
+// (:350-440), and five files PREFIX.<ctx>.<i> receive 100 000 positives and 100 000 negatives each, drawn without
+// replacement, as "label<TAB>prediction<TAB>probability" (:580-611).  The reference draws with random_device seeds, so
+// its files are not reproducible; the counts behind them are: `-d` (ours) writes the thresholds and the
+// counts[context][label][scaled_prob] table before thinning, `-s` (ours) fixes the seed of every draw.
+int cmd_eval(int argc, char** argv) {
+    uint64_t seed = std::random_device{}();
+    std::string dump_path;
+    int device = 0;
+    int a = 2;
+    for (; a + 1 < argc && argv[a][0] == '-' && argv[a][1]; a += 2) {
+        const std::string k = argv[a];
+        if (k == "-s") seed = strtoull(argv[a + 1], nullptr, 10);
+        else if (k == "-d") dump_path = argv[a + 1];
+        else if (k == "-g") device = atoi(argv[a + 1]);
+        else { fprintf(stderr, "ERROR: unrecognised option %s\n", argv[a]); return 1; }
+    }
+    if (argc - a != 4) {
+        fprintf(stderr, "USAGE:\n%s %s [-s seed] [-d counts.json] [-g device] reference bismark mod-bam output-prefix\n", argv[0], argv[1]);
+        return 1;
+    }
+    const char* ref_path = argv[a];
+    const char* bed_path = argv[a + 1];
+    const char* bam_path = argv[a + 2];
+    const std::string prefix = argv[a + 3];
+    constexpr uint64_t kTarget = 100000;
+    static const char* cn[3] = {"CpG", "CHG", "CHH"};
+
+    Fasta fa;
+    std::string err;
+    if (!load_fasta(ref_path, fa, err)) { fprintf(stderr, "ERROR: %s\n", err.c_str()); return EXIT_FAILURE; }
+    if (fa.names.empty()) { fprintf(stderr, "ERROR: no sequence in %s\n", ref_path); return EXIT_FAILURE; }
+    std::vector<int64_t> start(fa.names.size() + 1, 0);
+    for (size_t s = 0; s < fa.names.size(); ++s) start[s + 1] = start[s] + fa.length[s];
+
+    // truth labels (s_fill_chr_base_label_with_bismark, eval.cpp:42-114)
+    std::vector<int8_t> labels(fa.bases.size(), (int8_t)-1);
+    {
+        gzFile in = gzopen(bed_path, "rb");
+        if (!in) { fprintf(stderr, "ERROR: cannot open %s\n", bed_path); return EXIT_FAILURE; }
+        static char line[1 << 16];
+        std::string last;
+        int sid = -1;
+        size_t np = 0, nn = 0;
+        while (gzgets(in, line, sizeof line)) {
+            size_t ll = strlen(line);
+            while (ll && (line[ll - 1] == '\n' || line[ll - 1] == '\r')) line[--ll] = 0;
+            if (!ll) continue;
+            char* col[6];
+            int nc = 0;
+            char* p = line;
+            col[nc++] = p;
+            for (; *p && nc < 6; ++p)
+                if (*p == '\t') { *p = 0; col[nc++] = p + 1; }
+            if (nc < 6) { fprintf(stderr, "ERROR: corrupted bismark record %s\n", line); gzclose(in); return EXIT_FAILURE; }
+            if (sid < 0 || last != col[0]) {
+                last = col[0];
+                sid = fa.find(last);
+                if (sid < 0) { fprintf(stderr, "ERROR: sequence %s is not in %s\n", col[0], ref_path); gzclose(in); return EXIT_FAILURE; }
+            }
+            const int64_t soff = atoll(col[1]), send = atoll(col[2]);
+            if (send - soff != 1 || soff < 0 || soff >= fa.length[(size_t)sid]) {
+                fprintf(stderr, "ERROR: bad interval %s:%s-%s\n", col[0], col[1], col[2]);
+                gzclose(in);
+                return EXIT_FAILURE;
+            }
+            const int pcov = atoi(col[4]), ncov = atoi(col[5]);
+            if (pcov + ncov < 10) continue;
+            if (pcov == 0) { labels[(size_t)(start[(size_t)sid] + soff)] = 0; ++nn; }
+            else if (ncov == 0) { labels[(size_t)(start[(size_t)sid] + soff)] = 1; ++np; }
+        }
+        gzclose(in);
+        fprintf(stderr, "Load %zu methylated sites and %zu unmethylated sites from %s\n", np, nn, bed_path);
+    }
+
+    BgzfReader in(bam_path, 8);
+    BamHeader hdr;
+    if (!in.ok() || !read_header(in, hdr, err)) { fprintf(stderr, "ERROR: %s%s\n", in.error().c_str(), err.c_str()); return EXIT_FAILURE; }
+    std::vector<int> tid2sid(hdr.refs.size(), -2);
+    hm_pileup_t* pe = nullptr;
+    if (hm_pileup_create(&pe, device) != HM_OK) { fprintf(stderr, "ERROR: %s\n", hm_pileup_last_error(nullptr)); return EXIT_FAILURE; }
+    auto die = [&](const std::string& what) {
+        fprintf(stderr, "ERROR: %s: %s\n", what.c_str(), hm_pileup_last_error(pe));
+        hm_pileup_destroy(pe);
+        return EXIT_FAILURE;
+    };
+    if (hm_pileup_set_reference(pe, (int32_t)fa.names.size(), fa.length.data(), fa.bases.data()) != HM_OK) return die("reference");
+
+    // one pass: the threshold histograms count every primary record with calls, mapped or not (s_prob_bin_thread,
+    // eval.cpp:153-211) -- the engine counts the records it is given, the unmapped ones are counted here --; the samples
+    // come from the mapped ones, without mapQ / identity filters (:484-489)
+    static uint64_t extra[768];
+    std::fill(extra, extra + 768, 0);
+    constexpr int kBatch = 512;
+    std::vector<BamRecord> recs((size_t)kBatch);
+    std::vector<std::vector<BaseMod>> mods((size_t)kBatch);
+    std::vector<std::string> perr((size_t)kBatch);
+    std::vector<uint32_t> cig;
+    uint64_t order = 0;
+    bool more = true;
+    while (more) {
+        int n = 0;
+        while (n < kBatch && (more = read_record(in, recs[(size_t)n], err))) ++n;
+        if (!err.empty()) { fprintf(stderr, "ERROR: Could not read BAM record: %s\n", err.c_str()); hm_pileup_destroy(pe); return EXIT_FAILURE; }
+        parallel_run(n, 8, [&](int k) {
+            mods[(size_t)k].clear();
+            perr[(size_t)k].clear();
+            if (!parse_mods(recs[(size_t)k], mods[(size_t)k], perr[(size_t)k])) mods[(size_t)k].clear();
+        });
+        for (int k = 0; k < n; ++k, ++order) {
+            const BamRecord& r = recs[(size_t)k];
+            if (!perr[(size_t)k].empty()) {
+                fprintf(stderr, "ERROR at parsing read %s\n%s\n", reinterpret_cast<const char*>(r.data.data() + 32), perr[(size_t)k].c_str());
+                hm_pileup_destroy(pe);
+                return EXIT_FAILURE;
+            }
+            if (mods[(size_t)k].empty()) continue;
+            if (r.flag() & 4) {
+                if (!(r.flag() & 0x900))
+                    for (const BaseMod& m : mods[(size_t)k]) {
+                        const int c = mod_context(r, m.qoff);
+                        if (c >= 0) ++extra[c * 256 + m.prob];
+                    }
+                continue;
+            }
+            const int tid = r.ref_id();
+            if (tid < 0 || tid >= (int)hdr.refs.size()) { fprintf(stderr, "ERROR: mapped record without a reference id\n"); hm_pileup_destroy(pe); return EXIT_FAILURE; }
+            if (tid2sid[(size_t)tid] == -2) tid2sid[(size_t)tid] = fa.find(hdr.refs[(size_t)tid].first);
+            if (tid2sid[(size_t)tid] < 0) {
+                fprintf(stderr, "ERROR: Sequence name %s does not exist\n", hdr.refs[(size_t)tid].first.c_str());
+                hm_pileup_destroy(pe);
+                return EXIT_FAILURE;
+            }
+            cig.resize((size_t)r.n_cigar());
+            if (!cig.empty()) memcpy(cig.data(), r.cigar_bytes(), 4 * cig.size());
+            if (hm_pileup_submit_read(pe, (uint32_t)order, r.flag(), tid2sid[(size_t)tid], r.pos(), r.mapq(), r.l_qseq(), r.seq4(),
+                                      r.n_cigar(), cig.data(), (int64_t)mods[(size_t)k].size(), mods[(size_t)k].data()) < 0)
+                return die(std::string("read ") + reinterpret_cast<const char*>(r.data.data() + 32));
+        }
+        if (hm_pileup_run(pe) != HM_OK) return die("projection");
+    }
+    static uint64_t bins[768];
+    if (hm_pileup_histograms(pe, bins) != HM_OK) return die("histograms");
+    for (int i = 0; i < 768; ++i) bins[i] += extra[i];
+    uint8_t thr[3];
+    report_thresholds(bins, thr);
+
+    static uint64_t cnt[1536];  // [ctx][label][prob]
+    if (hm_pileup_label_histograms(pe, labels.data(), (int64_t)labels.size(), cnt) != HM_OK) return die("labels");
+    hm_pileup_destroy(pe);
+    if (!dump_path.empty()) {
+        FILE* f = fopen(dump_path.c_str(), "w");
+        if (!f) { fprintf(stderr, "ERROR: cannot open %s for writing\n", dump_path.c_str()); return EXIT_FAILURE; }
+        fprintf(f, "{\"thresholds\": [%d, %d, %d], \"counts\": [", thr[0], thr[1], thr[2]);
+        for (int i = 0; i < 1536; ++i) fprintf(f, "%s%llu", i ? ", " : "", (unsigned long long)cnt[i]);
+        fprintf(f, "]}\n");
+        fclose(f);
+    }
+
+    std::mt19937_64 gen(seed);
+    for (int c = 0; c < 3; ++c) {
+        uint64_t* neg = cnt + (c * 2 + 0) * 256;
+        uint64_t* pos = cnt + (c * 2 + 1) * 256;
+        if (c == 2)  // every unmethylated CHH sample is kept with probability 0.1 (:556)
+            for (int i = 0; i < 256; ++i)
+                if (neg[i]) neg[i] = std::binomial_distribution<uint64_t>(neg[i], 0.1)(gen);
+        uint64_t total[2] = {0, 0};
+        for (int i = 0; i < 256; ++i) { total[0] += neg[i]; total[1] += pos[i]; }
+        for (int l = 1; l >= 0; --l) {  // over_sampling_eval_samples (:350-440): positives first, as the messages come
+            uint64_t* h = l ? pos : neg;
+            if (total[l] > 0 && total[l] < kTarget) {
+                fprintf(stderr, "Original %s %s samples: %llu\n", cn[c], l ? "positive" : "negative", (unsigned long long)total[l]);
+                const uint64_t x = 2 * kTarget / total[l] * 2;
+                for (int i = 0; i < 256; ++i) h[i] *= x;
+                total[l] *= x;
+                fprintf(stderr, "Over-sampled %s %s samples: %llu\n", cn[c], l ? "positive" : "negative", (unsigned long long)total[l]);
+            }
+        }
+        if (total[0] == 0 || total[1] == 0) continue;
+        fprintf(stderr, "%s positive samples: %llu, negative samples: %llu\n", cn[c], (unsigned long long)total[1], (unsigned long long)total[0]);
+        // kTarget samples without replacement from a multiset given by its histogram: distinct ranks (Floyd), rank -> bin
+        auto draw = [&](const uint64_t* h, uint64_t n, std::vector<uint8_t>& out) {
+            std::vector<uint64_t> cum(257, 0);
+            for (int i = 0; i < 256; ++i) cum[(size_t)i + 1] = cum[(size_t)i] + h[i];
+            std::vector<uint64_t> picks;
+            picks.reserve(kTarget);
+            std::unordered_set<uint64_t> seen;
+            seen.reserve(2 * kTarget);
+            for (uint64_t j = n - kTarget; j < n; ++j) {
+                const uint64_t t = std::uniform_int_distribution<uint64_t>(0, j)(gen);
+                const uint64_t v = seen.insert(t).second ? t : j;
+                if (v == j && t != j) seen.insert(j);
+                picks.push_back(v);
+            }
+            std::shuffle(picks.begin(), picks.end(), gen);
+            out.clear();
+            for (uint64_t r : picks) out.push_back((uint8_t)(std::upper_bound(cum.begin(), cum.end(), r) - cum.begin() - 1));
+        };
+        std::vector<uint8_t> sp, sn;
+        for (int i = 0; i < 5; ++i) {  // s_dump_samples (:580-611)
+            const std::string path = prefix + "." + cn[c] + "." + std::to_string(i);
+            FILE* f = fopen(path.c_str(), "w");
+            if (!f) { fprintf(stderr, "ERROR: cannot open %s for writing\n", path.c_str()); return EXIT_FAILURE; }
+            draw(pos, total[1], sp);
+            draw(neg, total[0], sn);
+            for (uint8_t v : sp) fprintf(f, "1\t%d\t%g\n", v >= thr[c] ? 1 : 0, 1.0 * v / 255);
+            for (uint8_t v : sn) fprintf(f, "0\t%d\t%g\n", v >= thr[c] ? 1 : 0, 1.0 * v / 255);
+            fclose(f);
+        }
+    }
+    return 0;
+}
+
 // fastats REF.fa : names, lengths and a checksum of the loaded reference as one JSON object (loader tests; no GPU)
 int cmd_fastats(int argc, char** argv) {
     if (argc != 3) return EXIT_FAILURE;
@@ -393,6 +615,26 @@ int cmd_fastats(int argc, char** argv) {
     printf("]}\n");
     return 0;
 }
+
+namespace {
+// s_resolve_scaled_prob_threshold (pileup.cpp:355-436, eval.cpp:213-305): the three thresholds with the reference's messages
+void report_thresholds(const uint64_t* bins, uint8_t thr[3]) {
+    static const char* cn[3] = {"CpG", "CHG", "CHH"};
+    for (int c = 0; c < 3; ++c) {
+        uint64_t samples = 0;
+        const int t = resolve_threshold(bins + 256 * c, &samples);
+        fprintf(stderr, "%s samples: %llu\n", cn[c], (unsigned long long)samples);
+        const uint64_t* a = bins + 256 * c;  // the fallback branch: window narrower than 50 bins or < 10000 samples
+        int st = 20, en = 256 - 20;
+        while (st < 256 && a[st] < 10) ++st;
+        while (en && a[en - 1] < 10) --en;
+        const bool fallback = samples < 10000 || en - st < 50;
+        if (fallback) fprintf(stderr, "Not enough samples for inferring scaled probability threshold, set it to 128\n");
+        else fprintf(stderr, "%s scaled probability threshold: %d\n", cn[c], t);
+        thr[c] = (uint8_t)t;
+    }
+}
+}  // namespace
 
 int cmd_pileup(int argc, char** argv) {
     PileupOptions o;
@@ -528,19 +770,7 @@ int cmd_pileup(int argc, char** argv) {
     if (hm_pileup_histograms(pe, bins) != HM_OK) return die("histograms");
     uint8_t thr[3];
     static const char* cn[3] = {"CpG", "CHG", "CHH"};
-    for (int c = 0; c < 3; ++c) {  // s_resolve_scaled_prob_threshold (pileup.cpp:355-436)
-        uint64_t samples = 0;
-        const int t = resolve_threshold(bins + 256 * c, &samples);
-        fprintf(stderr, "%s samples: %llu\n", cn[c], (unsigned long long)samples);
-        const uint64_t* a = bins + 256 * c;  // the fallback branch: window narrower than 50 bins or < 10000 samples
-        int st = 20, en = 256 - 20;
-        while (st < 256 && a[st] < 10) ++st;
-        while (en && a[en - 1] < 10) --en;
-        const bool fallback = samples < 10000 || en - st < 50;
-        if (fallback) fprintf(stderr, "Not enough samples for inferring scaled probability threshold, set it to 128\n");
-        else fprintf(stderr, "%s scaled probability threshold: %d\n", cn[c], t);
-        thr[c] = (uint8_t)t;
-    }
+    report_thresholds(bins, thr);
     if (hm_pileup_count(pe, thr) != HM_OK) return die("count");
 
     FILE* out[3];

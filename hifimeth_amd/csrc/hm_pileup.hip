@@ -288,6 +288,25 @@ __global__ __launch_bounds__(TPB) void count_kernel(const PRec* __restrict__ rec
     }
 }
 
+// ---- resident records joined with per-locus truth labels (`hifimeth eval`, src/app/hifimeth/eval.cpp:469-560) ----
+// labels[g]: -1 no truth, 0 unmethylated, 1 methylated.  bins[(motif * 2 + label) * 256 + prob] counts the records whose
+// locus carries a label; workgroup-private histogram in LDS, one global atomic per non-empty bin and workgroup.
+__global__ __launch_bounds__(TPB) void label_kernel(const PRec* __restrict__ recs, int64_t n, const int8_t* __restrict__ labels,
+                                                     unsigned long long* __restrict__ bins) {
+    __shared__ uint32_t h[1536];
+    for (int i = threadIdx.x; i < 1536; i += TPB) h[i] = 0u;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const PRec r = recs[i];
+        const int64_t g = (int64_t)r.glo | ((int64_t)(r.hi & 255u) << 32);
+        const int lab = labels[g];
+        if (lab >= 0) atomicAdd(&h[(((r.hi >> 16) & 3u) * 2u + (lab ? 1u : 0u)) * 256u + ((r.hi >> 8) & 255u)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1536; i += TPB)
+        if (h[i]) atomicAdd(&bins[i], (unsigned long long)h[i]);
+}
+
 // ---- covered loci of a range, ascending ---------------------------------------------------------------------
 constexpr int LOCI_PER_BLOCK = 4096;  // 16 per thread
 
@@ -394,7 +413,7 @@ struct hm_pileup {
 
     // device
     DevBuf d_slab, d_reads, d_runs, d_col0, d_mods, d_plane, d_matches, d_bins, d_counter, d_recs;
-    DevBuf d_blk, d_offs, d_loci;
+    DevBuf d_blk, d_offs, d_loci, d_labels, d_lbins;
     int64_t n_recs = 0;
     bool bins_ready = false;
 };
@@ -730,6 +749,29 @@ int64_t hm_pileup_fetch_records(hm_pileup_t* p, int64_t* gpos, uint8_t* prob, ui
         if (order) order[i] = h[i].order;
     }
     return p->n_recs;
+}
+
+int hm_pileup_label_histograms(hm_pileup_t* p, const int8_t* labels, int64_t n_labels, uint64_t* bins1536) {
+    if (!p || !labels || !bins1536) return HM_EINVAL;
+    if (p->seq_off.empty()) return pfail(p, HM_ESTATE, "hm_pileup_label_histograms before hm_pileup_set_reference");
+    if (n_labels != p->seq_off.back()) return pfail(p, HM_EINVAL, "hm_pileup_label_histograms: one label per reference base expected");
+    try {
+        HIP_TRY(hipSetDevice(p->device));
+        p->d_labels.reserve((size_t)n_labels + 1);
+        p->d_lbins.reserve(1536 * sizeof(unsigned long long));
+        HIP_TRY(hipMemcpyAsync(p->d_labels.p, labels, (size_t)n_labels, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipMemsetAsync(p->d_lbins.p, 0, 1536 * sizeof(unsigned long long), p->stream));
+        if (p->n_recs) {
+            hipLaunchKernelGGL(label_kernel, dim3(grid_for(p->n_recs, 1024)), dim3(TPB), 0, p->stream, p->d_recs.as<PRec>(), p->n_recs,
+                               p->d_labels.as<int8_t>(), p->d_lbins.as<unsigned long long>());
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemcpyAsync(bins1536, p->d_lbins.p, 1536 * sizeof(uint64_t), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    } catch (const HipErr& h) {
+        return pfail_hip(p, h);
+    }
+    return HM_OK;
 }
 
 int hm_pileup_count(hm_pileup_t* p, const uint8_t thr[3]) {

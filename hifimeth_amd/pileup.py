@@ -158,6 +158,15 @@ class MethylationPileup:
         self._check(self._L.hm_pileup_fetch_records(self._h, *(x.ctypes.data_as(C.c_void_p) for x in (g, p, m, o)), n))
         return g, p, m, o
 
+    def label_histograms(self, labels: np.ndarray) -> np.ndarray:
+        """`hifimeth eval` (eval.cpp:469-560): resident records joined with per-locus truth labels (int8 over the
+        concatenated reference: -1 none, 0 unmethylated, 1 methylated) -> counts[motif, label, scaled_prob]"""
+        lab = np.ascontiguousarray(labels, np.int8)
+        b = np.zeros(1536, np.uint64)
+        self._check(self._L.hm_pileup_label_histograms(self._h, lab.ctypes.data_as(C.c_void_p), lab.size,
+                                                       b.ctypes.data_as(C.c_void_p)))
+        return b.reshape(3, 2, 256)
+
     @staticmethod
     def resolve_thresholds(bins) -> List[int]:
         return [resolve_threshold(bins[c])[0] for c in range(3)]

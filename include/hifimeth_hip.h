@@ -183,6 +183,10 @@ int hm_pileup_histograms(hm_pileup_t* p, uint64_t* bins768);
 /* debug / tests: D2H of the projected calls (unordered): gpos, prob, motif, order */
 int64_t hm_pileup_fetch_records(hm_pileup_t* p, int64_t* gpos, uint8_t* prob, uint8_t* motif, uint32_t* order,
                                 int64_t cap);
+/* `hifimeth eval` (src/app/hifimeth/eval.cpp:469-560): joins the resident records with per-locus truth labels --
+ * labels[g] over the concatenated reference: -1 none, 0 unmethylated, 1 methylated (s_fill_chr_base_label_with_bismark,
+ * eval.cpp:42-114) -- into bins[(motif * 2 + label) * 256 + scaled_prob].  The records stay resident. */
+int hm_pileup_label_histograms(hm_pileup_t* p, const int8_t* labels, int64_t n_labels, uint64_t* bins1536);
 /* zero-free accumulate of all resident records into the planes with the given per-context thresholds
  * (prob >= thr -> pcov else ncov; key = max(order << 2 | motif)); then drops the records */
 int hm_pileup_count(hm_pileup_t* p, const uint8_t thr[3]);

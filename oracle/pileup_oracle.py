@@ -346,6 +346,53 @@ def cov_to_bed(chrs, context, cov_text):
     return "".join(out), fs, rs
 
 
+# ---- helpers: eval (src/app/hifimeth/eval.cpp) -- restated by reading, PARITY UNPINNED (htslib-bound, and its output
+# files are drawn with random_device seeds); only the deterministic part is restated: thresholds and sample counts
+def bismark_labels(chrs, bed_text):
+    """s_fill_chr_base_label_with_bismark (eval.cpp:42-114): {(sid, soff): 0 | 1} from 0-based BED rows
+    chr, start, end, freq, pcov, ncov -- rows with < 10 reads or mixed calls carry no label"""
+    names = [n for n, _ in chrs]
+    lab = {}
+    for line in bed_text.split("\n"):
+        if not line:
+            continue
+        col = line.split("\t")
+        sid, soff, send, pc, nc = names.index(col[0]), int(col[1]), int(col[2]), int(col[4]), int(col[5])
+        assert send - soff == 1
+        if pc + nc < 10:
+            continue
+        if pc == 0:
+            lab[(sid, soff)] = 0
+        elif nc == 0:
+            lab[(sid, soff)] = 1
+    return lab
+
+
+def eval_counts(records, chrs, labels):
+    """-> (bins[3][256] of s_prob_bin_thread (eval.cpp:153-211: every primary record with calls, mapped or not),
+           thresholds, counts[3][2][256] of s_read_level_sample_thread (eval.cpp:469-560) before the CHH thinning)"""
+    bins = np.zeros((3, 256), np.uint64)
+    cnt = np.zeros((3, 2, 256), np.uint64)
+    for rec in records:
+        fwd, _ = fwd_rev(rec["seq"], rec["flag"])
+        mods = parse_mods(fwd, rec.get("mm"), rec.get("ml"))
+        if not mods:
+            continue
+        if not rec["flag"] & 0x900:
+            for q, _s, _ub, _code, prob in mods:
+                c = mod_context(fwd, q)
+                if c >= 0:
+                    bins[c, prob] += 1
+        if rec["flag"] & 4:
+            continue
+        _h, recs = read_contribution(rec, chrs)           # no mapQ / identity filter in eval (:484-489)
+        for sid, soff, prob, motif in recs:
+            lab = labels.get((sid, soff))
+            if lab is not None:
+                cnt[motif, lab, prob] += 1
+    return bins, [resolve_threshold(bins[c])[0] for c in range(3)], cnt
+
+
 # ---- the reference's own alignment code (oracle/_ref/ref_align), used to pin the functions above ---------------
 def ref_align_available():
     import os
