@@ -98,10 +98,38 @@ struct ConvH {
         __device__ __forceinline__ void operator()(int) const {}
     };
 
+    // The first HB k-blocks of a wave's weights, kept in registers for the whole launch (they are the same for every site):
+    // a layer then starts its k-loop straight after the barrier instead of waiting one L2 round trip for them.
+    template <int HB>
+    struct Head {
+        half8 w[HB > 0 ? HB : 1][NTW][2];
+        float4 bz[NTW];
+    };
+    template <int HB>
+    static __device__ __forceinline__ void load_head(const half_t* __restrict__ wfrag, const float* __restrict__ bias, Head<HB>& h) {
+        constexpr int WSTR = KSTACK ? 64 : 128;
+        const int tid = threadIdx.x;
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        if (WM * WN < NW && wave >= WM * WN) return;
+        const int wn = WM == 1 ? wave : wave % WN;
+        const half8* wp = reinterpret_cast<const half8*>(wfrag) + (size_t)(wn * NTW) * KB * WSTR + lane;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) h.bz[j] = *reinterpret_cast<const float4*>(bias + (wn * NTW + j) * 16 + 4 * (lane >> 4));
+#pragma unroll
+        for (int r = 0; r < HB; ++r)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                h.w[r][j][0] = wp[(size_t)(j * KB + r) * WSTR];
+                if (WLO && !KSTACK) h.w[r][j][1] = wp[(size_t)(j * KB + r) * WSTR + 64];
+            }
+    }
+
     // `mark(0)` after the prologue loads are issued, `mark(1)` after the k-loop (diagnostic stamps only)
-    template <class Epi, class Mark = NoMark>
+    template <class Epi, class Mark = NoMark, int HB = 0>
     static __device__ __forceinline__ void run(const half_t* __restrict__ in_hi, const half_t* __restrict__ in_lo,
-                                               const half_t* __restrict__ wfrag, Epi epi, Mark mark = Mark{}) {
+                                               const half_t* __restrict__ wfrag, Epi epi, Mark mark = Mark{},
+                                               const Head<HB>* head = nullptr) {
+        static_assert(HB <= BR - 1, "the head cannot be deeper than the prologue's share of the ring");
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));  // keep this layer's address arithmetic out of the persistent site loop
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,7 +167,7 @@ struct ConvH {
         f32x4 acc[MTW][NTW];
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-            const float4 bz = *reinterpret_cast<const float4*>(epi.bias + (wn * NTW + j) * 16 + 4 * lk);
+            const float4 bz = HB > 0 ? head->bz[j] : *reinterpret_cast<const float4*>(epi.bias + (wn * NTW + j) * 16 + 4 * lk);
 #pragma unroll
             for (int i = 0; i < MTW; ++i) acc[i][j] = f32x4{bz.x, bz.y, bz.z, bz.w};
         }
@@ -152,6 +180,11 @@ struct ConvH {
         for (int r = 0; r < BR - 1; ++r)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
+                if (r < HB) {
+                    wq[r][j][0] = head->w[r < HB ? r : 0][j][0];
+                    if (WLO && !KSTACK) wq[r][j][1] = head->w[r < HB ? r : 0][j][1];
+                    continue;
+                }
                 wq[r][j][0] = wp[(size_t)(j * KB + r) * WSTR];
                 if (WLO && !KSTACK) wq[r][j][1] = wp[(size_t)(j * KB + r) * WSTR + 64];
             }
@@ -431,6 +464,8 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
     // the one-hot base (0 / 1) and the four decoded frame counts / 32 (integers <= 952 scaled by a power of two) -- in one
     // plane; rows outside the read and the conv padding are all zeros
     constexpr bool FOLD = RAW;
+    constexpr int HB4V = 2;
+    constexpr bool HEADS = RAW;  // the float-window seam (tests) keeps the plain prologues
     auto build_window_f = [&](const SiteCtx& cx, const int t, const int nt) __attribute__((always_inline)) {
         const int L = cx.L, qoff = cx.qoff, rev = cx.rev;
         const int64_t bo = cx.bo;
@@ -483,6 +518,19 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         if constexpr (FOLD) build_window_f(cx, t, nt);
         else build_window(s, t, nt);
     };
+    using C2 = ConvH<NW, 128, 3, 128, G::L2, G::RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 1>;
+    using C3 = ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 1>;
+    using C4 = ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 4, 1, 0, 0, !W16, true, false, 0, true, 1>;
+    using C1 = ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, G::L1, G::WRS, 1, 8, 3, 1, 0, 0, true, false, true, K1, true>;
+    constexpr int HB1 = HEADS ? 2 : 0, HB2 = HEADS ? 2 : 0, HB3 = HEADS ? 2 : 0, HB4 = HEADS ? HB4V : 0;
+    typename C1::template Head<HB1> h1;
+    if constexpr (FOLD) C1::load_head(reinterpret_cast<const half_t*>(W.c1f), W.c1f_bias, h1);
+    typename C2::template Head<HB2> h2;
+    typename C3::template Head<HB3> h3;
+    typename C4::template Head<HB4> h4;
+    C2::load_head(reinterpret_cast<const half_t*>(W.wfrag_h[1]), W.bias[1], h2);
+    C3::load_head(reinterpret_cast<const half_t*>(W.wfrag_h[2]), W.bias[2], h3);
+    C4::load_head(reinterpret_cast<const half_t*>(W.wfrag_h[3]), W.bias[3], h4);
     if ((int)blockIdx.x < n_sites) build_any(blockIdx.x, fetch_ctx(blockIdx.x), threadIdx.x, NW * 64);
     SiteCtx ncx{0, 0, 0, 0};
     for (int s = blockIdx.x; s < n_sites; s += gridDim.x) {
@@ -493,9 +541,8 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
 
         // conv1: window (planes B) -> planes A
         if constexpr (FOLD)
-            ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, G::L1, G::WRS, 1, 8, 3, 1, 0, 0, true, false, true, K1, true>::run(
-                b_hi, b_hi, reinterpret_cast<const half_t*>(W.c1f), EpiPlanesC1<G::RS, G::L1>{a_hi, a_lo, W.c1f_bias, W.c1f_corr},
-                [&](int k) __attribute__((always_inline)) { mk(2 + k); });
+            C1::run(b_hi, b_hi, reinterpret_cast<const half_t*>(W.c1f), EpiPlanesC1<G::RS, G::L1>{a_hi, a_lo, W.c1f_bias, W.c1f_corr},
+                    [&](int k) __attribute__((always_inline)) { mk(2 + k); }, &h1);
         else
         ConvH<NW, 8, G::KT1, 128, G::L1, G::WRS, 2, 4, 3>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[0]),
                                                              EpiPlanes<G::RS>{a_hi, a_lo, W.bias[0]}, [&](int k) __attribute__((always_inline)) { mk(2 + k); });
@@ -513,8 +560,8 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         if (dbg && dbg_layer == 1 && s == 0) dump_planes<G::L1, 128, G::RS>(a_hi, a_lo, dbg);
 
         // conv2: planes A -> planes B
-        ConvH<NW, 128, 3, 128, G::L2, G::RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 1>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]),
-                                                           EpiPlanes<G::RS>{b_hi, b_lo, W.bias[1]}, [&](int k) __attribute__((always_inline)) { mk(6 + k); });
+        C2::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]), EpiPlanes<G::RS>{b_hi, b_lo, W.bias[1]},
+                [&](int k) __attribute__((always_inline)) { mk(6 + k); }, &h2);
         mk(8);
         zero_rows_h<128>(b_hi, b_lo, 0, G::L2 + 1, G::RS);
         __syncthreads();
@@ -522,8 +569,8 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         if (dbg && dbg_layer == 2 && s == 0) dump_planes<G::L2, 128, G::RS>(b_hi, b_lo, dbg);
 
         // conv3: planes B -> planes A
-        ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 1>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]),
-                                                           EpiPlanes<G::RS>{a_hi, a_lo, W.bias[2]}, [&](int k) __attribute__((always_inline)) { mk(10 + k); });
+        C3::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]), EpiPlanes<G::RS>{a_hi, a_lo, W.bias[2]},
+                [&](int k) __attribute__((always_inline)) { mk(10 + k); }, &h3);
         mk(12);
         zero_rows_h<128>(a_hi, a_lo, 0, G::L3 + 1, G::RS);
         __syncthreads();
@@ -532,8 +579,8 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
 
         // conv4: planes A -> act4[s] (fp32, hand-off to the tail kernel) on 6 waves (one 16-channel tile column
         // each, weights 3 k-blocks ahead); the other 2 build the next site's window in planes B meanwhile
-        ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 4, 1, 0, 0, !W16, true, false, 0, true, 1>::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]),
-                                                            EpiGlobalF<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]}, [&](int k) __attribute__((always_inline)) { mk(14 + k); });
+        C4::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]), EpiGlobalF<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]},
+                [&](int k) __attribute__((always_inline)) { mk(14 + k); }, &h4);
         mk(16);
         const int sn = s + gridDim.x;
         if (sn < n_sites && (int)threadIdx.x >= 384) build_any(sn, ncx, threadIdx.x - 384, 128);
