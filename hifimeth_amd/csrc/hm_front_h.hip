@@ -520,9 +520,9 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
     };
     using C2 = ConvH<NW, 128, 3, 128, G::L2, G::RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 1>;
     using C3 = ConvH<NW, 128, 3, 128, G::L3, G::RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 1>;
-    using C4 = ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 4, 1, 0, 0, !W16, true, false, 0, true, 1>;
-    using C1 = ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, G::L1, G::WRS, 1, 8, 3, 1, 0, 0, true, false, true, K1, true>;
-    constexpr int HB1 = HEADS ? 2 : 0, HB2 = HEADS ? 2 : 0, HB3 = HEADS ? 2 : 0, HB4 = HEADS ? HB4V : 0;
+    using C4 = ConvH<NW, 128, 3, C4_CH, G::L4, G::RS, 1, 6, 3, 1, 0, 0, !W16, true, false, 0, true, 1>;
+    using C1 = ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, G::L1, G::WRS, 1, 8, 4, 1, 0, 0, true, false, true, K1, true>;
+    constexpr int HB1 = HEADS ? 3 : 0, HB2 = HEADS ? 2 : 0, HB3 = HEADS ? 2 : 0, HB4 = HEADS ? HB4V : 0;
     typename C1::template Head<HB1> h1;
     if constexpr (FOLD) C1::load_head(reinterpret_cast<const half_t*>(W.c1f), W.c1f_bias, h1);
     typename C2::template Head<HB2> h2;
