@@ -29,11 +29,12 @@ typedef _Float16 half_t;
 
 typedef __fp16 pk2 __attribute__((ext_vector_type(2)));
 
-// max(x, 0) as ONE instruction (v_med3_f32 x, 0, +inf): fmaxf() makes the compiler quiet a possible signalling NaN first
-// (an extra v_max_f32 x, x, x per value).  A compiler builtin, NOT inline asm: x is an MFMA result, and the wait states an
+// max(x, 0) as ONE instruction (v_med3_f32 x, 0, 3e38): fmaxf() makes the compiler quiet a possible signalling NaN first
+// (an extra v_max_f32 x, x, x per value) -- and with +inf as the upper bound it rewrites the med3 into that same pair, hence
+// the finite bound, far above any activation.  A compiler builtin, NOT inline asm: x is an MFMA result, and the wait states an
 // MFMA result needs before a VALU read are only inserted for instructions the compiler can see -- an asm v_max_f32 placed
 // right behind the MFMAs of its tile read stale accumulators.
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 3.0e38f); }
 
 // lo halves of two values: fp16(x - hi) with v_fma_mix{lo,hi}_f16 -- the f16 half is widened inside the instruction,
 // subtracted from the fp32 x exactly and the residual rounded once (2 instructions instead of 2 cvt + 2 sub + 1 cvt_pk)
@@ -170,6 +171,16 @@ struct ConvH {
             const float4 bz = HB > 0 ? head->bz[j] : *reinterpret_cast<const float4*>(epi.bias + (wn * NTW + j) * 16 + 4 * lk);
 #pragma unroll
             for (int i = 0; i < MTW; ++i) acc[i][j] = f32x4{bz.x, bz.y, bz.z, bz.w};
+            if constexpr (EDGE) {
+                // the folded constant must not count where the first / last output row reaches the zero padding: it comes
+                // off those two rows' accumulators here, from registers the caller filled before the barrier (in the
+                // epilogue the two loads sat in a divergent branch with their latency exposed)
+                static_assert(WM == 1 && S == 1 && NTW == 1, "EDGE assumes one channel tile per wave over all positions");
+                const float f0 = li == 0 ? 1.f : 0.f, f1 = (MTW - 1) * 16 + li == M - 1 ? 1.f : 0.f;
+                acc[0][j][0] -= f0 * epi.c0.x; acc[0][j][1] -= f0 * epi.c0.y; acc[0][j][2] -= f0 * epi.c0.z; acc[0][j][3] -= f0 * epi.c0.w;
+                acc[MTW - 1][j][0] -= f1 * epi.c1.x; acc[MTW - 1][j][1] -= f1 * epi.c1.y;
+                acc[MTW - 1][j][2] -= f1 * epi.c1.z; acc[MTW - 1][j][3] -= f1 * epi.c1.w;
+            }
         }
 
         // weights: [n-tile][k-block][plane hi/lo][lane] half8
@@ -283,13 +294,6 @@ struct ConvH {
             const int m = tile * 16 + li;
             const bool full = WM == 1 ? (i + 1) * 16 <= M : false;
             if (full || m < M) {
-                if constexpr (EDGE) {
-                    if (tile == 0 || tile == (M - 1) / 16) {
-#pragma unroll
-                        for (int j = 0; j < NTW; ++j) epi.edge(m, (wn * NTW + j) * 16 + 4 * lk, acc[i][j]);
-                        continue;
-                    }
-                }
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) epi(m, (wn * NTW + j) * 16 + 4 * lk, acc[i][j]);
             }
@@ -328,20 +332,12 @@ struct EpiPlanesC1 {
     half_t* hi;
     half_t* lo;
     const float* __restrict__ bias;
-    const float* __restrict__ corr;  // [2][128]
+    float4 c0, c1;  // this lane's four channels of the pad-row corrections [2][128] (see ConvH, EDGE)
     __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
         half4 h, l;
         split4(acc, h, l);
         *reinterpret_cast<half4*>(hi + (m + 1) * ORS + col) = h;
         *reinterpret_cast<half4*>(lo + (m + 1) * ORS + col) = l;
-    }
-    // tiles holding output row 0 or LOUT-1
-    __device__ __forceinline__ void edge(int m, int col, f32x4 acc) const {
-        if (m == 0 || m == LOUT - 1) {
-            const float4 c = *reinterpret_cast<const float4*>(corr + (m ? 128 : 0) + col);
-            acc[0] -= c.x; acc[1] -= c.y; acc[2] -= c.z; acc[3] -= c.w;
-        }
-        (*this)(m, col, acc);
     }
 };
 
@@ -536,12 +532,18 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
     for (int s = blockIdx.x; s < n_sites; s += gridDim.x) {
         if (STAMP) tprev = hm_stamp();
         mk(0);
+        float4 cr0 = make_float4(0.f, 0.f, 0.f, 0.f), cr1 = cr0;
+        if constexpr (FOLD) {  // conv1's pad-row corrections for this lane's channels: requested before the barrier, used at its accumulator init
+            const int ccol = (threadIdx.x >> 6) * 16 + 4 * ((threadIdx.x & 63) >> 4);
+            cr0 = *reinterpret_cast<const float4*>(W.c1f_corr + ccol);
+            cr1 = *reinterpret_cast<const float4*>(W.c1f_corr + 128 + ccol);
+        }
         __syncthreads();  // window of site s complete; previous conv4 done with planes A
         mk(1);
 
         // conv1: window (planes B) -> planes A
         if constexpr (FOLD)
-            C1::run(b_hi, b_hi, reinterpret_cast<const half_t*>(W.c1f), EpiPlanesC1<G::RS, G::L1>{a_hi, a_lo, W.c1f_bias, W.c1f_corr},
+            C1::run(b_hi, b_hi, reinterpret_cast<const half_t*>(W.c1f), EpiPlanesC1<G::RS, G::L1>{a_hi, a_lo, W.c1f_bias, cr0, cr1},
                     [&](int k) __attribute__((always_inline)) { mk(2 + k); }, &h1);
         else
         ConvH<NW, 8, G::KT1, 128, G::L1, G::WRS, 2, 4, 3>::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[0]),
