@@ -559,7 +559,9 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         zero_rows_h<128>(a_hi, a_lo, 0, G::L1 + 1, G::RS);
         __syncthreads();
         mk(5);
-        if (dbg && dbg_layer == 1 && s == 0) dump_planes<G::L1, 128, G::RS>(a_hi, a_lo, dbg);
+        if constexpr (!RAW) {  // the layer dump only exists on the float-window seam (hm_debug_layer)
+            if (dbg && dbg_layer == 1 && s == 0) dump_planes<G::L1, 128, G::RS>(a_hi, a_lo, dbg);
+        }
 
         // conv2: planes A -> planes B
         C2::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[1]), EpiPlanes<G::RS>{b_hi, b_lo, W.bias[1]},
@@ -568,7 +570,9 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         zero_rows_h<128>(b_hi, b_lo, 0, G::L2 + 1, G::RS);
         __syncthreads();
         mk(9);
-        if (dbg && dbg_layer == 2 && s == 0) dump_planes<G::L2, 128, G::RS>(b_hi, b_lo, dbg);
+        if constexpr (!RAW) {  // the layer dump only exists on the float-window seam (hm_debug_layer)
+            if (dbg && dbg_layer == 2 && s == 0) dump_planes<G::L2, 128, G::RS>(b_hi, b_lo, dbg);
+        }
 
         // conv3: planes B -> planes A
         C3::run(b_hi, b_lo, reinterpret_cast<const half_t*>(W.wfrag_h[2]), EpiPlanes<G::RS>{a_hi, a_lo, W.bias[2]},
@@ -577,7 +581,9 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         zero_rows_h<128>(a_hi, a_lo, 0, G::L3 + 1, G::RS);
         __syncthreads();
         mk(13);
-        if (dbg && dbg_layer == 3 && s == 0) dump_planes<G::L3, 128, G::RS>(a_hi, a_lo, dbg);
+        if constexpr (!RAW) {  // the layer dump only exists on the float-window seam (hm_debug_layer)
+            if (dbg && dbg_layer == 3 && s == 0) dump_planes<G::L3, 128, G::RS>(a_hi, a_lo, dbg);
+        }
 
         // conv4: planes A -> act4[s] (fp32, hand-off to the tail kernel) on 6 waves (one 16-channel tile column
         // each, weights 3 k-blocks ahead); the other 2 build the next site's window in planes B meanwhile
