@@ -618,6 +618,20 @@ struct EpiPlanesS {
     }
 };
 
+// conv8's output for the batched fc1: rows 0..LOUT-1 of a site back to back (no padding rows), [site][LOUT][ORS]
+template <int LOUT, int ORS>
+struct EpiRing {
+    half_t* hi;
+    half_t* lo;
+    const float* __restrict__ bias;
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        half4 h, l;
+        split4(acc, h, l);
+        *reinterpret_cast<half4*>(hi + m * ORS + col) = h;
+        *reinterpret_cast<half4*>(lo + m * ORS + col) = l;
+    }
+};
+
 template <int HRS>
 struct EpiFc1 {  // ReLU, fp32 h[site][256] for the VALU fc2
     float* out;
@@ -636,8 +650,11 @@ struct TailGeoH {
     static constexpr int C7_SS = (L7 + 2) * RS64, C8_SS = (L8 + 2) * RS64;
     static constexpr int P0 = S * IN_SS;  // plane size of buffer 0 (also conv6 / conv8 outputs)
     static constexpr int P1 = S * C5_SS;  // plane size of buffer 1 (also conv7 output; fc1 output as floats)
-    static_assert(S * C6_SS <= P0 && S * C8_SS <= P0 && S * C7_SS <= P1 && S * HRS * 2 <= 2 * P1, "tail LDS plan");
-    static constexpr int LDS_HALVES = 2 * P0 + 2 * P1;
+    // fc1 + fc2 run once per FCB groups: conv8's outputs wait in a ring (one plane = FCB * S sites x 2 rows), so the
+    // 131 KB of fc1 weights -- the largest fetch of the tail for its smallest matrix job -- stream once per FCB * S sites
+    static constexpr int FCB = 4, RING_SS = L8 * RS64, RING = FCB * S * RING_SS;
+    static_assert(S * C6_SS <= P0 && S * C7_SS <= P1 && FCB * S * HRS * 2 <= 2 * P1, "tail LDS plan");
+    static constexpr int LDS_HALVES = 2 * P0 + 2 * P1 + 2 * RING;
 };
 
 template <int S, int LOUT, int C>
@@ -664,6 +681,9 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
     half_t* h1 = smem + 2 * T::P0;
     half_t* l1 = smem + 2 * T::P0 + T::P1;
     float* hfc = reinterpret_cast<float*>(h1);  // fc1 activations (fp32) reuse buffer 1
+    half_t* r_hi = smem + 2 * T::P0 + 2 * T::P1;
+    half_t* r_lo = r_hi + T::RING;
+    constexpr int FCB = T::FCB;
     __shared__ float fc2w[2 * 256 + 2];          // fc2 weights + bias stay in LDS for the whole kernel
     for (int i = threadIdx.x; i < 2 * 256 + 2; i += NW * 64) fc2w[i] = i < 512 ? W.fc2_w[i] : W.fc2_b[i - 512];
     auto wf = [&](int i) { return reinterpret_cast<const half_t*>(W.wfrag_h[i]); };
@@ -684,9 +704,8 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         }
     };
     if ((int)blockIdx.x * S < n_sites) fetch(blockIdx.x);
+    int slot = 0, g_first = blockIdx.x;  // groups g_first, g_first + gridDim.x, ... wait in ring slots 0 .. slot-1
     for (int g = blockIdx.x; g * S < n_sites; g += gridDim.x) {
-        const int s0 = g * S;
-        const int nv = min(S, n_sites - s0);
         // act4 [site][25][96] fp32 -> split planes 0, rows 1..25
 #pragma unroll
         for (int k = 0; k < NPRE; ++k) {
@@ -726,18 +745,29 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         if (dbg && dbg_layer == 7 && g == 0) dump_planes<T::L7, 64, T::RS64>(h1, l1, dbg);
 
         ConvH<NW, 64, 3, 64, T::L8, T::RS64, 1, 4, 3, S, T::C7_SS, 0, !W16>::run(
-            h1, l1, wf(7), EpiPlanesS<T::L8, T::RS64, T::C8_SS>{h0, l0, W.bias[7]});
+            h1, l1, wf(7), EpiRing<T::L8, T::RS64>{r_hi + slot * S * T::RING_SS, r_lo + slot * S * T::RING_SS, W.bias[7]});
+        if (slot == 0) g_first = g;
+        ++slot;
+        if (dbg && dbg_layer == 8 && g == 0) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < T::L8 * 64; i += NW * 64) {
+                const int o = (i / 64) * T::RS64 + (i % 64);
+                dbg[i] = (float)r_hi[o] + (float)r_lo[o];
+            }
+        }
+        if (slot < FCB && (g + (int)gridDim.x) * S < n_sites) continue;  // the loop-top barrier orders this conv8 before the next conv5
         __syncthreads();
-        if (dbg && dbg_layer == 8 && g == 0) dump_planes<T::L8, 64, T::RS64>(h0, l0, dbg);
 
-        // fc1 as a 2-tap "conv" over conv8's two positions (k order l*64 + c; see hm_weights.cpp)
-        ConvH<NW, 64, 2, 256, 1, T::RS64, 1, 8, 2, S, T::C8_SS, 1>::run(h0, l0, wf(8), EpiFc1<T::HRS>{hfc, W.bias[8]});
+        // fc1 as a 2-tap "conv" over conv8's two positions (k order l*64 + c; see hm_weights.cpp), FCB * S sites at once;
+        // slots this batch did not fill hold stale rows whose results are never written out
+        ConvH<NW, 64, 2, 256, 1, T::RS64, 1, 8, 2, FCB * S, T::RING_SS, 0>::run(r_hi, r_lo, wf(8), EpiFc1<T::HRS>{hfc, W.bias[8]});
         __syncthreads();
 
         // fc2 + softmax (mod_batch.cpp:46-64) in fp32: 16 lanes per site = 2 outputs x 8 partial sums
-        if (threadIdx.x < S * 16) {
-            const int site = threadIdx.x >> 4, o = (threadIdx.x >> 3) & 1, part = threadIdx.x & 7;
-            const float* h = hfc + site * T::HRS + part * 32;
+        {
+            static_assert(FCB * S * 16 == NW * 64, "one 16-lane team per site");
+            const int bsite = threadIdx.x >> 4, o = (threadIdx.x >> 3) & 1, part = threadIdx.x & 7;
+            const float* h = hfc + bsite * T::HRS + part * 32;
             const float* w2 = fc2w + o * 256 + part * 32;
             float sum = 0.f;
 #pragma unroll 8
@@ -747,21 +777,23 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
             sum += __shfl_xor(sum, 1, 64);
             sum += fc2w[512 + o];
             const float other = __shfl_xor(sum, 8, 64);
-            if ((threadIdx.x & 15) == 0 && site < nv) {
+            const int sl = bsite / S, site = bsite - sl * S;
+            const int gs0 = (g_first + sl * (int)gridDim.x) * S;
+            if ((threadIdx.x & 15) == 0 && sl < slot && gs0 + site < n_sites) {
                 const float v0 = sum, v1 = other;
                 const float mx = fmaxf(v0, v1);
                 const float e0 = expf(v0 - mx), e1 = expf(v1 - mx);
                 const float p1 = e1 / (e0 + e1);
                 int q = (int)(255 * p1);
                 q = q > 255 ? 255 : q;
-                const int dst = sites ? sites[s0 + site].uidx : s0 + site;
+                const int dst = sites ? sites[gs0 + site].uidx : gs0 + site;
                 logits[2 * (size_t)dst] = v0;
                 logits[2 * (size_t)dst + 1] = v1;
                 prob[dst] = p1;
                 ml[dst] = (uint8_t)q;
             }
         }
-        __syncthreads();
+        slot = 0;  // hfc (buffer 1) and the ring are next written behind the loop-top barrier / the conv7 barrier
     }
 }
 
