@@ -586,7 +586,7 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
         }
 
         // conv4: planes A -> act4[s] (fp32, hand-off to the tail kernel) on 6 waves (one 16-channel tile column
-        // each, weights 3 k-blocks ahead); the other 2 build the next site's window in planes B meanwhile
+        // each, its first two weight k-blocks resident, the rest two blocks ahead); the other 2 build the next site's window in planes B meanwhile
         C4::run(a_hi, a_lo, reinterpret_cast<const half_t*>(W.wfrag_h[3]), EpiGlobalF<C4_CH>{act4 + (size_t)s * ACT4_FLOATS, W.bias[3]},
                 [&](int k) __attribute__((always_inline)) { mk(14 + k); }, &h4);
         mk(16);
