@@ -25,7 +25,12 @@ class hm_timing_t(C.Structure):
                 ("front_ms", C.c_double * 3), ("tail_ms", C.c_double * 3),
                 ("prep_launches", C.c_int64), ("scan_launches", C.c_int64), ("emit_launches", C.c_int64),
                 ("window_launches", C.c_int64), ("front_launches", C.c_int64 * 3), ("tail_launches", C.c_int64 * 3),
-                ("front_sites", C.c_int64 * 3), ("window_sites", C.c_int64)]
+                ("front_sites", C.c_int64 * 3), ("window_sites", C.c_int64),
+                ("pack_ms", C.c_double), ("empty_ms", C.c_double),
+                ("pack_launches", C.c_int64), ("empty_launches", C.c_int64),
+                ("trunk_ms", C.c_double * 3), ("edge_ms", C.c_double * 3),
+                ("trunk_launches", C.c_int64 * 3), ("edge_launches", C.c_int64 * 3),
+                ("trunk_positions", C.c_int64 * 3)]
 
 
 def build(force: bool = False) -> str:
@@ -69,6 +74,14 @@ def lib():
         "hm_fetch": (i64, [vp, vp, i64]),
         "hm_flush": (C.c_int, [vp]),
         "hm_drain": (i64, [vp, vp, i64]),
+        "hm_batch_begin": (vp, [vp]),
+        "hm_batch_submit_read": (C.c_int, [vp, i32, i32, i32, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int]),
+        "hm_batch_staged_bases": (i64, [vp]),
+        "hm_batch_enqueue": (C.c_int, [vp]),
+        "hm_batch_done": (C.c_int, [vp]),
+        "hm_batch_wait": (i64, [vp, C.POINTER(vp)]),
+        "hm_batch_num_sites": (i64, [vp, C.c_int]),
+        "hm_batch_release": (C.c_int, [vp]),
         "hm_scan_sites": (i64, [vp, C.c_int, vp, vp, vp, i64]),
         "hm_windows": (C.c_int, [vp, C.c_int, i64, i64, vp]),
         "hm_cnn_logits": (C.c_int, [vp, C.c_int, vp, i64, vp, vp, vp]),

@@ -81,9 +81,8 @@ class MethylationCaller:
         self._check(self._L.hm_set_option(self._h, key.encode(), int(value)), f"hm_set_option({key})")
 
     # -- staging (EvalKmerFeaturesGenerator::init) ------------------------------------------------
-    def submit(self, read_id: int, read) -> bool:
-        """`read`: object with l_qseq, flag, seq4 and fi/fp/ri/rp (uint8 or uint16 arrays, or None).
-        True if accepted, False if passed through uncalled (short read / missing kinetics)."""
+    @staticmethod
+    def _read_args(read):
         arrs, widths = [], []
         for nm in ("fi", "fp", "ri", "rp"):
             a = getattr(read, nm)
@@ -97,10 +96,14 @@ class MethylationCaller:
             arrs.append(a)
             widths.append(1 if a is None else a.dtype.itemsize)
         seq4 = np.ascontiguousarray(read.seq4, np.uint8)
-        rc = self._L.hm_submit_read(self._h, read_id, read.l_qseq, read.flag, _vp(seq4),
-                                    _vp(arrs[0]), widths[0], _vp(arrs[1]), widths[1],
-                                    _vp(arrs[2]), widths[2], _vp(arrs[3]), widths[3])
-        return bool(self._check(rc, "hm_submit_read"))
+        return (read.l_qseq, read.flag, _vp(seq4), _vp(arrs[0]), widths[0], _vp(arrs[1]), widths[1],
+                _vp(arrs[2]), widths[2], _vp(arrs[3]), widths[3]), (seq4, arrs)
+
+    def submit(self, read_id: int, read) -> bool:
+        """`read`: object with l_qseq, flag, seq4 and fi/fp/ri/rp (uint8 or uint16 arrays, or None).
+        True if accepted, False if passed through uncalled (short read / missing kinetics)."""
+        args, _keep = self._read_args(read)
+        return bool(self._check(self._L.hm_submit_read(self._h, read_id, *args), "hm_submit_read"))
 
     def submit_all(self, reads: Iterable, first_id: int = 0) -> int:
         n = 0
@@ -140,6 +143,42 @@ class MethylationCaller:
         out = self.fetch()
         self.clear()
         return out
+
+    # -- asynchronous batch pipeline (hm_batch_*) --------------------------------------------------------
+    def begin_batch(self) -> "Batch":
+        """A free slot of the engine's pipeline (blocks while all slots are staged or in flight)."""
+        h = self._L.hm_batch_begin(self._h)
+        if not h:
+            raise HifimethError(f"hm_batch_begin failed: {self._L.hm_last_error(self._h).decode()}")
+        return Batch(self, h)
+
+    def stream(self, slabs: Iterable, on_batch=None) -> int:
+        """Runs every slab (an iterable of reads) through the pipeline: slab k+1 is staged and uploaded while slab k
+        computes; results are collected in order.  `on_batch(k, batch, calls)` sees each slab's CALL_DTYPE records (a
+        view of pinned memory that is only valid inside the callback).  Returns the total number of calls."""
+        inflight, total, k_done = [], 0, 0
+
+        def collect(b):
+            nonlocal total, k_done
+            calls = b.wait()
+            total += len(calls)
+            if on_batch is not None:
+                on_batch(k_done, b, calls)
+            k_done += 1
+            b.release()
+
+        for slab in slabs:
+            b = self.begin_batch()
+            b.submit_all(slab)
+            b.enqueue()
+            inflight.append(b)
+            while len(inflight) > 1 and (inflight[0].done() or len(inflight) >= self.max_inflight):
+                collect(inflight.pop(0))
+        while inflight:
+            collect(inflight.pop(0))
+        return total
+
+    max_inflight = 3
 
     # -- seams -------------------------------------------------------------------------------------
     def scan_sites(self, ctx: int):
@@ -185,3 +224,46 @@ class MethylationCaller:
         if reset:
             self._L.hm_reset_timing(self._h)
         return d
+
+
+class Batch:
+    """One slot of the engine's pipeline: stage -> enqueue (returns at once) -> wait -> release."""
+
+    def __init__(self, mc: MethylationCaller, handle):
+        self._mc, self._L, self._h = mc, mc._L, C.c_void_p(handle)
+
+    def submit(self, read_id: int, read) -> bool:
+        args, _keep = MethylationCaller._read_args(read)
+        return bool(self._mc._check(self._L.hm_batch_submit_read(self._h, read_id, *args), "hm_batch_submit_read"))
+
+    def submit_all(self, reads: Iterable, first_id: int = 0) -> int:
+        n = 0
+        for i, r in enumerate(reads):
+            n += self.submit(first_id + i, r)
+        return n
+
+    def staged_bases(self) -> int:
+        return self._L.hm_batch_staged_bases(self._h)
+
+    def enqueue(self):
+        self._mc._check(self._L.hm_batch_enqueue(self._h), "hm_batch_enqueue")
+
+    def done(self) -> bool:
+        return bool(self._mc._check(self._L.hm_batch_done(self._h), "hm_batch_done"))
+
+    def num_sites(self, ctx: int = 3) -> int:
+        return self._mc._check(self._L.hm_batch_num_sites(self._h, ctx), "hm_batch_num_sites")
+
+    def wait(self) -> np.ndarray:
+        """The batch's calls as a CALL_DTYPE view of the slot's pinned result buffer (valid until release())."""
+        ptr = C.c_void_p()
+        n = self._mc._check(self._L.hm_batch_wait(self._h, C.byref(ptr)), "hm_batch_wait")
+        if n == 0:
+            return np.empty(0, CALL_DTYPE)
+        buf = (C.c_char * (n * CALL_DTYPE.itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, CALL_DTYPE, n)
+
+    def release(self):
+        if self._h:
+            self._L.hm_batch_release(self._h)
+            self._h = None

@@ -40,6 +40,19 @@ struct USite {
     int32_t qoff;
 };
 
+// per-chunk site counters / their exclusive scans: CpG, CHG, CHH, all contexts, reverse-strand sites (CHH on a G)
+constexpr int NCNT = 5;
+
+// Where a CNN launch finds its sites.  When a batch is queued its site counts exist only on the device (no host round
+// trip between the scanner and the CNN): a launch names a context and a window [off, off + cap) of that context's
+// list, and every workgroup resolves the actual pointer and count from the scan kernel's totals.
+// totals == nullptr: `base` is the list itself (or nullptr for caller-supplied windows) and `cap` the exact count.
+struct SiteRange {
+    const Site* base;       // the three per-context lists back to back
+    const int32_t* totals;  // [0..2] sites per context, [3] all, [4..6] first element of each context's list
+    int32_t ctx, off, cap;
+};
+
 // bn0 folded into lookup tables, computed on the host with the ONNX BatchNormalization
 // formula so that device windows equal the oracle's bn0 output bit for bit.
 struct BnTables {

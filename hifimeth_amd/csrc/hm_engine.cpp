@@ -1,12 +1,22 @@
-// hm_engine.cpp -- host side of libhifimeth_hip.so: model loading, read staging, batch
-// execution and the C ABI of include/hifimeth_hip.h.  Mirrors what ModModels, ModBatch and the
-// worker loop do around the hot path in the reference (src/app/hifimeth/mod_main.cpp:18-262).
+// hm_engine.cpp -- host side of libhifimeth_hip.so: model loading, read staging, the asynchronous batch pipeline
+// and the C ABI of include/hifimeth_hip.h.  Mirrors what ModModels, ModBatch and the worker loop do around the hot
+// path in the reference (src/app/hifimeth/mod_main.cpp:18-262); the pinned double-buffered staging follows the shape
+// of the reference's GPU variant (src/app-gpu/hifimeth-gpu/5mc_call_gpu.cpp:309-334,367) without its per-site windows.
+//
+// One engine = one device, one compute stream, N batch slots.  A slot owns pinned staging memory, the device buffers of
+// one batch and an I/O stream: queueing a batch enqueues   H2D (slot stream) -> scanner + CNN + pack (compute stream)
+// -> D2H of the totals (slot stream)   and returns -- no host/device synchronisation anywhere on the way.  The site
+// counts never come back to the host to size the CNN launches: the persistent CNN kernels read them from the scan
+// kernel's totals on the device (SiteRange), the host only bounds the launch windows by the number of staged bases.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,31 +63,37 @@ struct DevBuf {
     T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-struct PinnedBuf {
-    uint8_t* p = nullptr;
-    size_t cap = 0, size = 0;
-    void ensure(size_t extra) {
-        if (size + extra <= cap) return;
-        size_t want = std::max<size_t>((size + extra) * 2, size_t(64) << 20);
-        uint8_t* q = nullptr;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&q), want, hipHostMallocDefault));
-        if (size) memcpy(q, p, size);
+// grow-only pinned host array: what an asynchronous copy may read from / write to
+template <class T>
+struct PinnedArr {
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    void reserve(size_t want) {
+        if (want <= cap) return;
+        want = std::max(want + want / 2, size_t(4096) / sizeof(T) + 1);
+        T* q = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&q), want * sizeof(T), hipHostMallocDefault));
+        if (n) memcpy(q, p, n * sizeof(T));
         if (p) (void)hipHostFree(p);
         p = q;
         cap = want;
     }
+    void push_back(const T& v) {
+        if (n == cap) reserve(n + 1);
+        p[n++] = v;
+    }
     void release() {
         if (p) (void)hipHostFree(p);
         p = nullptr;
-        cap = size = 0;
+        n = cap = 0;
     }
 };
 
-enum Kind { K_PREP, K_SCAN, K_EMIT, K_WINDOW, K_FRONT0, K_FRONT1, K_FRONT2, K_TAIL0, K_TAIL1, K_TAIL2 };
+enum Kind { K_PREP, K_SCAN, K_EMIT, K_PACK, K_WINDOW, K_FRONT, K_TAIL };
 
 struct TimedSpan {
-    int kind;
-    int64_t sites;
+    int kind, ctx;
+    int64_t off, cap;  // CNN spans: launch window into the context's site list; K_WINDOW: cap = sites
     hipEvent_t a, b;
 };
 
@@ -90,6 +106,32 @@ struct DeviceModel {
 
 }  // namespace
 
+// One batch slot: staged reads (pinned), their device buffers, results.
+struct hm_batch {
+    hm_engine* e = nullptr;
+    int id = 0;
+    enum State { FREE, STAGING, QUEUED } state = FREE;
+    bool uploaded = false, ran = false, have_totals = false, have_calls = false;
+    hipStream_t s_io = nullptr;  // this slot's copies in and out
+    hipEvent_t ev_in = nullptr, ev_comp = nullptr, ev_out = nullptr;
+
+    // staged batch (host, pinned)
+    PinnedArr<uint8_t> slab;
+    PinnedArr<ReadDesc> reads;
+    PinnedArr<Chunk> chunks;
+    int64_t total_bases = 0;  // padded to a multiple of 4 per read
+
+    // device
+    DevBuf d_raw, d_reads, d_chunks, d_bases, d_kin, d_sctx, d_counts, d_offs, d_totals, d_err;
+    DevBuf d_usites, d_utag, d_csites, d_opos, d_logits, d_p, d_ml, d_calls;
+    int32_t* h_totals = nullptr;  // pinned [8]
+    int32_t* h_err = nullptr;     // pinned
+    PinnedArr<hm_call_t> h_calls;
+    int32_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    std::vector<TimedSpan> spans;
+};
+
 struct hm_engine {
     int device = 0;
     int num_cu = 256;
@@ -98,29 +140,22 @@ struct hm_engine {
     int64_t sub_batch = 65536;
     int front_waves = 8;
     int precision = 1;  // 1 = split-half f16x3 MFMA with fp32 accumulate (default), 0 = fp32 MFMA
+    int max_slots = 3;  // batch slots of the asynchronous API (the legacy calls use one more, slot 0)
     bool stamps_on = false;
     std::vector<unsigned long long> stamp_sum;
     bool timing = false;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // compute
     DeviceModel model[3];
     std::string err;
 
-    // staged batch (host)
-    PinnedBuf slab;
-    std::vector<ReadDesc> reads;
-    std::vector<Chunk> chunks;
-    int64_t total_bases = 0;  // padded to a multiple of 4 per read
-    bool uploaded = false, ran = false, synced = false;
+    std::mutex mu;  // slot states, error string, event pool, timing
+    std::mutex order_mu;  // the kernels of two batches must not interleave on the compute stream
+    std::condition_variable cv;
+    std::vector<std::unique_ptr<hm_batch>> slots;  // [0] = the batch of the legacy (synchronous) calls
 
-    // device
-    DevBuf d_raw, d_reads, d_chunks, d_bases, d_kin, d_counts, d_offs, d_totals, d_err;
-    DevBuf d_usites, d_utag, d_csites, d_logits, d_p, d_ml, d_act4, d_win, d_dbg, d_stamps;
-    int32_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int32_t* h_totals = nullptr;  // pinned
-    int32_t* h_err = nullptr;     // pinned
+    // scratch shared by all batches: only touched by kernels on the compute stream, which runs batches in order
+    DevBuf d_act4, d_win, d_dbg, d_stamps;
 
-    // timing
-    std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> pool;
     hm_timing_t acc{};
 };
@@ -128,8 +163,12 @@ struct hm_engine {
 namespace {
 
 int fail(hm_engine* e, int code, const std::string& msg) {
-    if (e) e->err = msg;
-    else g_create_error = msg;
+    if (e) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->err = msg;
+    } else {
+        g_create_error = msg;
+    }
     return code;
 }
 
@@ -138,10 +177,13 @@ int fail_hip(hm_engine* e, const HipErr& h) {
 }
 
 hipEvent_t get_event(hm_engine* e) {
-    if (!e->pool.empty()) {
-        hipEvent_t ev = e->pool.back();
-        e->pool.pop_back();
-        return ev;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!e->pool.empty()) {
+            hipEvent_t ev = e->pool.back();
+            e->pool.pop_back();
+            return ev;
+        }
     }
     hipEvent_t ev;
     HIP_TRY(hipEventCreate(&ev));
@@ -150,12 +192,16 @@ hipEvent_t get_event(hm_engine* e) {
 
 struct Span {
     hm_engine* e;
+    std::vector<TimedSpan>* sink;
     TimedSpan ts{};
     bool on;
-    Span(hm_engine* eng, int kind, int64_t sites) : e(eng), on(eng->timing) {
+    Span(hm_engine* eng, std::vector<TimedSpan>* out, int kind, int ctx = 0, int64_t off = 0, int64_t cap = 0)
+        : e(eng), sink(out), on(eng->timing && out) {
         if (!on) return;
         ts.kind = kind;
-        ts.sites = sites;
+        ts.ctx = ctx;
+        ts.off = off;
+        ts.cap = cap;
         ts.a = get_event(e);
         ts.b = get_event(e);
         HIP_TRY(hipEventRecord(ts.a, e->stream));
@@ -163,31 +209,38 @@ struct Span {
     void end() {
         if (!on) return;
         HIP_TRY(hipEventRecord(ts.b, e->stream));
-        e->spans.push_back(ts);
+        sink->push_back(ts);
         on = false;
     }
 };
 
-void collect_timing(hm_engine* e) {
-    for (auto& s : e->spans) {
+// spans of finished work -> accumulated timing; `totals` gives the site counts the CNN launch windows resolved to
+void collect_timing(hm_engine* e, std::vector<TimedSpan>& spans, const int32_t* totals) {
+    for (auto& s : spans) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
+        std::lock_guard<std::mutex> lk(e->mu);
         hm_timing_t& t = e->acc;
+        const int64_t n = totals ? std::clamp<int64_t>((int64_t)totals[s.ctx] - s.off, 0, s.cap) : s.cap;
         switch (s.kind) {
         case K_PREP: t.prep_ms += ms; ++t.prep_launches; break;
         case K_SCAN: t.scan_ms += ms; ++t.scan_launches; break;
         case K_EMIT: t.emit_ms += ms; ++t.emit_launches; break;
-        case K_WINDOW: t.window_ms += ms; ++t.window_launches; t.window_sites += s.sites; break;
-        case K_FRONT0: case K_FRONT1: case K_FRONT2:
-            t.front_ms[s.kind - K_FRONT0] += ms; ++t.front_launches[s.kind - K_FRONT0];
-            t.front_sites[s.kind - K_FRONT0] += s.sites; break;
+        case K_PACK: t.pack_ms += ms; ++t.pack_launches; break;
+        case K_WINDOW: t.window_ms += ms; ++t.window_launches; t.window_sites += s.cap; break;
+        case K_FRONT:
+            if (n > 0) { t.front_ms[s.ctx] += ms; ++t.front_launches[s.ctx]; t.front_sites[s.ctx] += n; }
+            else { t.empty_ms += ms; ++t.empty_launches; }
+            break;
         default:
-            t.tail_ms[s.kind - K_TAIL0] += ms; ++t.tail_launches[s.kind - K_TAIL0]; break;
+            if (n > 0) { t.tail_ms[s.ctx] += ms; ++t.tail_launches[s.ctx]; }
+            else { t.empty_ms += ms; ++t.empty_launches; }
+            break;
         }
         e->pool.push_back(s.a);
         e->pool.push_back(s.b);
     }
-    e->spans.clear();
+    spans.clear();
 }
 
 // ---- model -> device ----------------------------------------------------------------------
@@ -216,13 +269,6 @@ void upload_model(hm_engine* e, int ctx, const HostModel& hmw) {
 
 size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
 
-void ensure_site_buffers(hm_engine* e, int64_t n) {
-    const size_t nn = (size_t)std::max<int64_t>(n, 1);
-    e->d_logits.reserve(nn * 2 * sizeof(float));
-    e->d_p.reserve(nn * sizeof(float));
-    e->d_ml.reserve(nn);
-}
-
 // diagnostic: sum the per-wave phase stamps of the front launch that was just queued
 void accumulate_stamps(hm_engine* e) {
     const int ns = front_stamp_slots();
@@ -235,44 +281,274 @@ void accumulate_stamps(hm_engine* e) {
     for (size_t i = 0; i < n; ++i) e->stamp_sum[i % ((size_t)ns * 8)] += h[i];  // [wave in workgroup][slot]
 }
 
-// front + tail over `n` sites of one context, in sub-batches that bound the act4 hand-off buffer
-void run_cnn(hm_engine* e, int ctx, const Site* sites, const float* windows, int64_t n, float* dbg, int dbg_layer) {
+// One front + tail pair over the sites named by `sr`, results to logits / p / ml (indexed by uidx for staged reads,
+// by position for caller-supplied windows).
+void launch_cnn_pair(hm_engine* e, std::vector<TimedSpan>* spans, int ctx, const SiteRange& sr, const hm_batch* b,
+                     const float* windows, float* logits, float* p, uint8_t* ml, float* dbg, int dbg_layer) {
     const DeviceModel& dm = e->model[ctx];
+    const ReadDesc* reads = b ? b->d_reads.as<ReadDesc>() : nullptr;
+    const uint8_t* bases = b ? b->d_bases.as<uint8_t>() : nullptr;
+    const uint32_t* kin = b ? b->d_kin.as<uint32_t>() : nullptr;
+    {
+        Span sp(e, spans, K_FRONT, ctx, sr.off, sr.cap);
+        if (e->precision >= 1)
+            launch_front_h(e->stream, dm.k1, sr, reads, bases, kin, windows, dm.w, e->d_act4.as<float>(), e->num_cu, dbg,
+                           dbg_layer, e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr, e->precision == 2);
+        else
+            launch_front(e->stream, dm.k1, sr, reads, bases, kin, windows, dm.w, e->d_act4.as<float>(), e->num_cu, dbg,
+                         dbg_layer, e->front_waves, e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr);
+        if (e->stamps_on) accumulate_stamps(e);
+        sp.end();
+    }
+    {
+        Span sp(e, spans, K_TAIL, ctx, sr.off, sr.cap);
+        if (e->precision >= 1)
+            launch_tail_h(e->stream, e->d_act4.as<float>(), sr, dm.w, logits, p, ml, e->num_cu, dbg, dbg_layer,
+                          e->precision == 2);
+        else
+            launch_tail(e->stream, e->d_act4.as<float>(), sr, dm.w, logits, p, ml, e->num_cu, dbg, dbg_layer);
+        sp.end();
+    }
+}
+
+// CNN over the caller-supplied windows (the hm_cnn_logits / hm_debug_layer seam): exact counts, host-sized launches
+void run_cnn_windows(hm_engine* e, int ctx, const float* windows, int64_t n, float* logits, float* p, uint8_t* ml,
+                     float* dbg, int dbg_layer) {
     const int64_t sb = e->sub_batch;
     e->d_act4.reserve((size_t)std::min<int64_t>(std::max<int64_t>(n, 1), sb) * ACT4_FLOATS * sizeof(float));
+    std::vector<TimedSpan> spans;
     for (int64_t off = 0; off < n; off += sb) {
         const int m = (int)std::min<int64_t>(sb, n - off);
-        const Site* s_off = sites ? sites + off : nullptr;
-        const float* w_off = windows ? windows + (size_t)off * KMER * FEATS : nullptr;
-        {
-            Span sp(e, K_FRONT0 + ctx, m);
-            if (e->precision >= 1)
-                launch_front_h(e->stream, dm.k1, s_off, m, e->d_reads.as<ReadDesc>(), e->d_bases.as<uint8_t>(),
-                               e->d_kin.as<uint32_t>(), w_off, dm.w, e->d_act4.as<float>(), e->num_cu, dbg, dbg_layer,
-                               e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr, e->precision == 2);
-            else
-                launch_front(e->stream, dm.k1, s_off, m, e->d_reads.as<ReadDesc>(), e->d_bases.as<uint8_t>(),
-                             e->d_kin.as<uint32_t>(), w_off, dm.w, e->d_act4.as<float>(), e->num_cu, dbg, dbg_layer,
-                             e->front_waves, e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr);
-            if (e->stamps_on) accumulate_stamps(e);
-            sp.end();
-        }
-        {
-            Span sp(e, K_TAIL0 + ctx, m);
-            // results land at sites[i].uidx for staged reads, at off + i for caller-supplied windows
-            float* lg = e->d_logits.as<float>() + (sites ? 0 : 2 * off);
-            float* pp = e->d_p.as<float>() + (sites ? 0 : off);
-            uint8_t* mm = e->d_ml.as<uint8_t>() + (sites ? 0 : off);
-            if (e->precision >= 1)
-                launch_tail_h(e->stream, e->d_act4.as<float>(), m, dm.w, s_off, lg, pp, mm, e->num_cu, dbg, dbg_layer,
-                              e->precision == 2);
-            else
-                launch_tail(e->stream, e->d_act4.as<float>(), m, dm.w, s_off, lg, pp, mm, e->num_cu, dbg, dbg_layer);
-            sp.end();
-        }
+        const SiteRange sr{nullptr, nullptr, ctx, 0, m};
+        launch_cnn_pair(e, e->timing ? &spans : nullptr, ctx, sr, nullptr, windows + (size_t)off * KMER * FEATS,
+                        logits + 2 * off, p + off, ml + off, dbg, dbg_layer);
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    collect_timing(e, spans, nullptr);
 }
+
+// ---- batch slots ------------------------------------------------------------------------------------------------
+hm_batch* new_slot(hm_engine* e, int id) {
+    std::unique_ptr<hm_batch> b(new hm_batch());
+    b->e = e;
+    b->id = id;
+    HIP_TRY(hipStreamCreateWithFlags(&b->s_io, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&b->ev_comp, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&b->ev_out, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 8 * sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_err), sizeof(int32_t), hipHostMallocDefault));
+    memset(b->h_totals, 0, 8 * sizeof(int32_t));
+    *b->h_err = 0;
+    b->d_totals.reserve(8 * sizeof(int32_t));
+    b->d_err.reserve(sizeof(int32_t));
+    HIP_TRY(hipMemset(b->d_err.p, 0, sizeof(int32_t)));
+    HIP_TRY(hipMemset(b->d_totals.p, 0, 8 * sizeof(int32_t)));
+    hm_batch* raw = b.get();
+    e->slots.push_back(std::move(b));
+    return raw;
+}
+
+void free_slot(hm_batch* b) {
+    if (b->s_io) (void)hipStreamSynchronize(b->s_io);
+    for (DevBuf* d : {&b->d_raw, &b->d_reads, &b->d_chunks, &b->d_bases, &b->d_kin, &b->d_sctx, &b->d_counts, &b->d_offs,
+                      &b->d_totals, &b->d_err, &b->d_usites, &b->d_utag, &b->d_csites, &b->d_opos, &b->d_logits, &b->d_p,
+                      &b->d_ml, &b->d_calls})
+        d->release();
+    b->slab.release();
+    b->reads.release();
+    b->chunks.release();
+    b->h_calls.release();
+    if (b->h_totals) (void)hipHostFree(b->h_totals);
+    if (b->h_err) (void)hipHostFree(b->h_err);
+    for (auto& s : b->spans) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    for (hipEvent_t ev : {b->ev_in, b->ev_comp, b->ev_out})
+        if (ev) (void)hipEventDestroy(ev);
+    if (b->s_io) (void)hipStreamDestroy(b->s_io);
+}
+
+void reset_staging(hm_batch* b) {
+    b->slab.n = 0;
+    b->reads.n = 0;
+    b->chunks.n = 0;
+    b->total_bases = 0;
+    b->uploaded = b->ran = b->have_totals = b->have_calls = false;
+    memset(b->totals, 0, sizeof b->totals);
+}
+
+// EvalKmerFeaturesGenerator::init: copy one read into the slot's pinned slab exactly as the BAM record stores it
+int stage_read(hm_batch* b, int32_t read_id, int32_t l_qseq, int32_t flag, const uint8_t* seq4, const void* fi, int fi_w,
+               const void* fp, int fp_w, const void* ri, int ri_w, const void* rp, int rp_w) {
+    hm_engine* e = b->e;
+    if (l_qseq < 0) return HM_EINVAL;
+    if (l_qseq < e->min_read_size) return 0;        // mod_main.cpp:189-192
+    if (!fi || !fp || !ri || !rp) return 0;          // BamKinetics::init false (bam_info.cpp:572-603)
+    if (!seq4) return fail(e, HM_EINVAL, "hm_submit_read: seq4 is NULL");
+    // site ranks and per-base offsets inside one batch are 32-bit on the device: keep a batch under 2^31 bases
+    if (b->total_bases + (int64_t)l_qseq + 4 >= (int64_t(1) << 31))
+        return fail(e, HM_ENOMEM, "hm_submit_read: batch would exceed 2^31 bases; flush / queue it first");
+    const int w[4] = {fi_w, fp_w, ri_w, rp_w};
+    for (int k = 0; k < 4; ++k)
+        if (w[k] != 1 && w[k] != 2) return fail(e, HM_EINVAL, "kinetics element width must be 1 (B:C) or 2 (B:S)");
+    try {
+        HIP_TRY(hipSetDevice(e->device));  // the pinned allocations below belong to this engine's device
+        const size_t L = (size_t)l_qseq;
+        const size_t need = align16((L + 1) / 2) + align16(L * fi_w) + align16(L * fp_w) + align16(L * ri_w) + align16(L * rp_w);
+        if (b->slab.n + need > b->slab.cap) b->slab.reserve(std::max<size_t>((b->slab.n + need) * 2, size_t(64) << 20));
+        ReadDesc rd{};
+        auto put = [&](const void* src, size_t bytes) {
+            const int64_t off = (int64_t)b->slab.n;
+            memcpy(b->slab.p + off, src, bytes);
+            b->slab.n += align16(bytes);
+            return off;
+        };
+        rd.off_seq = put(seq4, (L + 1) / 2);
+        rd.off_fi = put(fi, L * fi_w);
+        rd.off_fp = put(fp, L * fp_w);
+        rd.off_ri = put(ri, L * ri_w);
+        rd.off_rp = put(rp, L * rp_w);
+        rd.base_off = b->total_bases;
+        rd.len = l_qseq;
+        rd.flag = flag;
+        rd.read_id = read_id;
+        for (int k = 0; k < 4; ++k) rd.w[k] = (uint8_t)w[k];
+        const int ridx = (int)b->reads.n;
+        b->reads.push_back(rd);
+        for (int st = 0; st < l_qseq; st += CHUNK) b->chunks.push_back(Chunk{ridx, st});
+        b->total_bases += (int64_t)((L + 3) & ~size_t(3));
+    } catch (const HipErr& h) {
+        return fail_hip(e, h);
+    }
+    return 1;
+}
+
+// staged slab + descriptors -> HBM, asynchronously on the slot's stream (everything it reads is pinned)
+void enqueue_upload(hm_batch* b) {
+    const size_t nr = b->reads.n, nc = b->chunks.n;
+    b->d_raw.reserve(std::max<size_t>(b->slab.n, 16));
+    b->d_reads.reserve(std::max<size_t>(nr, 1) * sizeof(ReadDesc));
+    b->d_chunks.reserve(std::max<size_t>(nc, 1) * sizeof(Chunk));
+    const size_t tb = (size_t)std::max<int64_t>(b->total_bases, 4);
+    b->d_bases.reserve(tb);
+    b->d_sctx.reserve(tb);
+    b->d_kin.reserve(tb * sizeof(uint32_t));
+    b->d_counts.reserve((nc + 1) * NCNT * sizeof(int32_t));
+    b->d_offs.reserve((nc + 1) * NCNT * sizeof(int32_t));
+    // every forward position carries at most one site over all contexts
+    b->d_usites.reserve(tb * sizeof(USite));
+    b->d_utag.reserve(tb);
+    b->d_csites.reserve(tb * sizeof(Site));
+    b->d_opos.reserve(tb * sizeof(int32_t));
+    b->d_logits.reserve(tb * 2 * sizeof(float));
+    b->d_p.reserve(tb * sizeof(float));
+    b->d_ml.reserve(tb);
+    b->d_calls.reserve(tb * sizeof(hm_call_t));
+    if (b->slab.n) HIP_TRY(hipMemcpyAsync(b->d_raw.p, b->slab.p, b->slab.n, hipMemcpyHostToDevice, b->s_io));
+    if (nr) HIP_TRY(hipMemcpyAsync(b->d_reads.p, b->reads.p, nr * sizeof(ReadDesc), hipMemcpyHostToDevice, b->s_io));
+    if (nc) HIP_TRY(hipMemcpyAsync(b->d_chunks.p, b->chunks.p, nc * sizeof(Chunk), hipMemcpyHostToDevice, b->s_io));
+    HIP_TRY(hipEventRecord(b->ev_in, b->s_io));
+    b->uploaded = true;
+    b->ran = b->have_totals = b->have_calls = false;
+}
+
+// scanner + CNN + pack on the compute stream, then the totals' D2H on the slot stream; returns without waiting
+void enqueue_run(hm_batch* b) {
+    hm_engine* e = b->e;
+    std::vector<TimedSpan>* spans = e->timing ? &b->spans : nullptr;
+    const int nc = (int)b->chunks.n;
+    HIP_TRY(hipStreamWaitEvent(e->stream, b->ev_in, 0));
+    {
+        Span sp(e, spans, K_PREP);
+        launch_prep(e->stream, b->d_raw.as<uint8_t>(), b->d_reads.as<ReadDesc>(), b->d_chunks.as<Chunk>(), nc, e->ctx_mask,
+                    b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), b->d_counts.as<int32_t>(),
+                    b->d_err.as<int32_t>());
+        sp.end();
+    }
+    {
+        Span sp(e, spans, K_SCAN);
+        launch_scan(e->stream, b->d_counts.as<int32_t>(), nc, b->d_offs.as<int32_t>(), b->d_totals.as<int32_t>());
+        sp.end();
+    }
+    {
+        Span sp(e, spans, K_EMIT);
+        launch_emit(e->stream, b->d_reads.as<ReadDesc>(), b->d_chunks.as<Chunk>(), nc, e->ctx_mask, b->d_bases.as<uint8_t>(),
+                    b->d_offs.as<int32_t>(), b->d_totals.as<int32_t>(), b->d_usites.as<USite>(), b->d_utag.as<uint8_t>(),
+                    b->d_csites.as<Site>(), b->d_opos.as<int32_t>());
+        sp.end();
+    }
+    // The CNN launches cover [0, bound) of every context's list in windows of `sb` sites; how many sites a window
+    // really holds is resolved on the device.  bound = staged bases (a position carries at most one site); the
+    // window grows with the batch so that a batch never needs more than ~48 launch pairs per context.
+    const int64_t bound = nc ? b->total_bases : 0;
+    int64_t sb = std::max<int64_t>(e->sub_batch, (bound / 48 + TAIL_SITES) / TAIL_SITES * TAIL_SITES);
+    sb = std::min<int64_t>(sb, int64_t(1) << 20);
+    e->d_act4.reserve((size_t)std::min<int64_t>(std::max<int64_t>(bound, 1), sb) * ACT4_FLOATS * sizeof(float));
+    for (int c = 0; c < 3; ++c) {
+        if (!(e->ctx_mask >> c & 1)) continue;
+        for (int64_t off = 0; off < bound; off += sb) {
+            const SiteRange sr{b->d_csites.as<Site>(), b->d_totals.as<int32_t>(), c, (int32_t)off,
+                               (int32_t)std::min<int64_t>(sb, bound - off)};
+            launch_cnn_pair(e, spans, c, sr, b, nullptr, b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(),
+                            nullptr, 0);
+        }
+    }
+    {
+        Span sp(e, spans, K_PACK);
+        const int grid = (int)std::clamp<int64_t>((bound / 3 + 255) / 256, 1, (int64_t)e->num_cu * 8);
+        launch_pack(e->stream, b->d_usites.as<USite>(), b->d_utag.as<uint8_t>(), b->d_opos.as<int32_t>(), b->d_p.as<float>(),
+                    b->d_ml.as<uint8_t>(), b->d_reads.as<ReadDesc>(), b->d_totals.as<int32_t>(), b->d_calls.p, grid);
+        sp.end();
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->ev_comp, e->stream));
+    HIP_TRY(hipStreamWaitEvent(b->s_io, b->ev_comp, 0));
+    HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals.p, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, b->s_io));
+    HIP_TRY(hipMemcpyAsync(b->h_err, b->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, b->s_io));
+    HIP_TRY(hipEventRecord(b->ev_out, b->s_io));
+    b->ran = true;
+    b->have_totals = b->have_calls = false;
+}
+
+// wait for THIS batch only: its totals are on the host afterwards; reports device-side data errors
+int wait_totals(hm_batch* b) {
+    hm_engine* e = b->e;
+    if (!b->ran) return HM_OK;
+    if (!b->have_totals) {
+        HIP_TRY(hipEventSynchronize(b->ev_out));
+        memcpy(b->totals, b->h_totals, sizeof b->totals);
+        b->have_totals = true;
+        collect_timing(e, b->spans, b->totals);
+    }
+    if (*b->h_err) {
+        *b->h_err = 0;
+        HIP_TRY(hipMemsetAsync(b->d_err.p, 0, sizeof(int32_t), b->s_io));
+        HIP_TRY(hipStreamSynchronize(b->s_io));
+        return fail(e, HM_EDATA, "illegal BAM base encoded value in a staged read");
+    }
+    return HM_OK;
+}
+
+// the batch's calls in pinned host memory: one packed D2H of exactly n records
+int fetch_calls(hm_batch* b) {
+    int rc = wait_totals(b);
+    if (rc < 0) return rc;
+    if (b->have_calls) return HM_OK;
+    const size_t n = (size_t)b->totals[3];
+    b->h_calls.reserve(std::max<size_t>(n, 1));
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(b->h_calls.p, b->d_calls.p, n * sizeof(hm_call_t), hipMemcpyDeviceToHost, b->s_io));
+        HIP_TRY(hipStreamSynchronize(b->s_io));
+    }
+    b->h_calls.n = n;
+    b->have_calls = true;
+    return HM_OK;
+}
+
+hm_batch* legacy(hm_engine* e) { return e->slots[0].get(); }
 
 }  // namespace
 
@@ -298,8 +574,6 @@ int hm_create(hm_engine_t** out, const char* model_dir, int ctx_mask, int device
         e->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         e->ctx_mask = ctx_mask & 7;
         HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_totals), 8 * sizeof(int32_t), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_err), sizeof(int32_t), hipHostMallocDefault));
         static const char* names[3] = {"CpG", "CHG", "CHH"};  // mod_main.cpp:76,85,94
         for (int c = 0; c < 3; ++c) {
             if (!(e->ctx_mask >> c & 1)) continue;
@@ -311,9 +585,7 @@ int hm_create(hm_engine_t** out, const char* model_dir, int ctx_mask, int device
             }
             upload_model(e, c, hmw);
         }
-        e->d_totals.reserve(8 * sizeof(int32_t));
-        e->d_err.reserve(sizeof(int32_t));
-        HIP_TRY(hipMemset(e->d_err.p, 0, sizeof(int32_t)));
+        new_slot(e, 0)->state = hm_batch::STAGING;
     } catch (const HipErr& h) {
         int rc = fail_hip(nullptr, h);
         hm_destroy(e);
@@ -327,18 +599,10 @@ void hm_destroy(hm_engine_t* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& b : e->slots) free_slot(b.get());
+    e->slots.clear();
     for (auto& m : e->model) m.params.release();
-    for (DevBuf* b : {&e->d_raw, &e->d_reads, &e->d_chunks, &e->d_bases, &e->d_kin, &e->d_counts, &e->d_offs,
-                      &e->d_totals, &e->d_err, &e->d_usites, &e->d_utag, &e->d_csites, &e->d_logits, &e->d_p,
-                      &e->d_ml, &e->d_act4, &e->d_win, &e->d_dbg, &e->d_stamps})
-        b->release();
-    e->slab.release();
-    if (e->h_totals) (void)hipHostFree(e->h_totals);
-    if (e->h_err) (void)hipHostFree(e->h_err);
-    for (auto& s : e->spans) {
-        (void)hipEventDestroy(s.a);
-        (void)hipEventDestroy(s.b);
-    }
+    for (DevBuf* b : {&e->d_act4, &e->d_win, &e->d_dbg, &e->d_stamps}) b->release();
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -372,64 +636,34 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
     } else if (k == "sub_batch_sites") {
         if (value < TAIL_SITES) return fail(e, HM_EINVAL, "sub_batch_sites too small");
         e->sub_batch = value / TAIL_SITES * TAIL_SITES;
+    } else if (k == "slots") {
+        if (value < 1 || value > 16) return fail(e, HM_EINVAL, "slots must be 1..16");
+        e->max_slots = (int)value;
     } else return fail(e, HM_EINVAL, "unknown option " + k);
     return HM_OK;
 }
 
+// ---- the synchronous calls: one implicit batch (slot 0) ------------------------------------------------------------
 int hm_submit_read(hm_engine_t* e, int32_t read_id, int32_t l_qseq, int32_t flag, const uint8_t* seq4,
                    const void* fi, int fi_w, const void* fp, int fp_w, const void* ri, int ri_w, const void* rp,
                    int rp_w) {
-    if (!e || l_qseq < 0) return HM_EINVAL;
-    if (e->uploaded) return fail(e, HM_ESTATE, "hm_submit_read: batch already uploaded; hm_clear first");
-    if (l_qseq < e->min_read_size) return 0;        // mod_main.cpp:189-192
-    if (!fi || !fp || !ri || !rp) return 0;          // BamKinetics::init false (bam_info.cpp:572-603)
-    if (!seq4) return fail(e, HM_EINVAL, "hm_submit_read: seq4 is NULL");
-    // site ranks and per-base offsets inside one batch are 32-bit on the device: keep a batch under 2^31 bases
-    if (e->total_bases + (int64_t)l_qseq + 4 >= (int64_t(1) << 31))
-        return fail(e, HM_ENOMEM, "hm_submit_read: batch would exceed 2^31 bases; hm_flush / hm_drain first");
-    const int w[4] = {fi_w, fp_w, ri_w, rp_w};
-    for (int k = 0; k < 4; ++k)
-        if (w[k] != 1 && w[k] != 2) return fail(e, HM_EINVAL, "kinetics element width must be 1 (B:C) or 2 (B:S)");
-    try {
-        const size_t L = (size_t)l_qseq;
-        const size_t need = align16((L + 1) / 2) + align16(L * fi_w) + align16(L * fp_w) + align16(L * ri_w) + align16(L * rp_w);
-        e->slab.ensure(need);
-        ReadDesc rd{};
-        auto put = [&](const void* src, size_t bytes) {
-            const int64_t off = (int64_t)e->slab.size;
-            memcpy(e->slab.p + off, src, bytes);
-            e->slab.size += align16(bytes);
-            return off;
-        };
-        rd.off_seq = put(seq4, (L + 1) / 2);
-        rd.off_fi = put(fi, L * fi_w);
-        rd.off_fp = put(fp, L * fp_w);
-        rd.off_ri = put(ri, L * ri_w);
-        rd.off_rp = put(rp, L * rp_w);
-        rd.base_off = e->total_bases;
-        rd.len = l_qseq;
-        rd.flag = flag;
-        rd.read_id = read_id;
-        for (int k = 0; k < 4; ++k) rd.w[k] = (uint8_t)w[k];
-        const int ridx = (int)e->reads.size();
-        e->reads.push_back(rd);
-        for (int st = 0; st < l_qseq; st += CHUNK) e->chunks.push_back(Chunk{ridx, st});
-        e->total_bases += (int64_t)((L + 3) & ~size_t(3));
-    } catch (const HipErr& h) {
-        return fail_hip(e, h);
-    }
-    return 1;
+    if (!e) return HM_EINVAL;
+    hm_batch* b = legacy(e);
+    if (b->uploaded) return fail(e, HM_ESTATE, "hm_submit_read: batch already uploaded; hm_clear first");
+    return stage_read(b, read_id, l_qseq, flag, seq4, fi, fi_w, fp, fp_w, ri, ri_w, rp, rp_w);
 }
 
 int hm_clear(hm_engine_t* e) {
     if (!e) return HM_EINVAL;
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
-    e->slab.size = 0;
-    e->reads.clear();
-    e->chunks.clear();
-    e->total_bases = 0;
-    e->uploaded = e->ran = e->synced = false;
-    memset(e->totals, 0, sizeof e->totals);
+    hm_batch* b = legacy(e);
+    (void)hipSetDevice(e->device);
+    if (b->ran && !b->have_totals) (void)hipEventSynchronize(b->ev_out);
+    if (b->s_io) (void)hipStreamSynchronize(b->s_io);
+    try {
+        collect_timing(e, b->spans, b->ran ? b->h_totals : nullptr);
+    } catch (const HipErr&) {
+    }
+    reset_staging(b);
     return HM_OK;
 }
 
@@ -437,25 +671,7 @@ int hm_upload(hm_engine_t* e) {
     if (!e) return HM_EINVAL;
     try {
         HIP_TRY(hipSetDevice(e->device));
-        const size_t nr = e->reads.size(), nc = e->chunks.size();
-        e->d_raw.reserve(std::max<size_t>(e->slab.size, 16));
-        e->d_reads.reserve(std::max<size_t>(nr, 1) * sizeof(ReadDesc));
-        e->d_chunks.reserve(std::max<size_t>(nc, 1) * sizeof(Chunk));
-        const size_t tb = (size_t)std::max<int64_t>(e->total_bases, 4);
-        e->d_bases.reserve(tb);
-        e->d_kin.reserve(tb * sizeof(uint32_t));
-        e->d_counts.reserve(std::max<size_t>(nc, 1) * 4 * sizeof(int32_t));
-        e->d_offs.reserve(std::max<size_t>(nc, 1) * 4 * sizeof(int32_t));
-        // every forward position carries at most one site over all contexts
-        e->d_usites.reserve(tb * sizeof(USite));
-        e->d_utag.reserve(tb);
-        e->d_csites.reserve(tb * sizeof(Site));
-        if (e->slab.size) HIP_TRY(hipMemcpyAsync(e->d_raw.p, e->slab.p, e->slab.size, hipMemcpyHostToDevice, e->stream));
-        if (nr) HIP_TRY(hipMemcpyAsync(e->d_reads.p, e->reads.data(), nr * sizeof(ReadDesc), hipMemcpyHostToDevice, e->stream));
-        if (nc) HIP_TRY(hipMemcpyAsync(e->d_chunks.p, e->chunks.data(), nc * sizeof(Chunk), hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));  // reads/chunks vectors are pageable: keep it simple and safe
-        e->uploaded = true;
-        e->ran = e->synced = false;
+        enqueue_upload(legacy(e));
     } catch (const HipErr& h) {
         return fail_hip(e, h);
     }
@@ -464,42 +680,15 @@ int hm_upload(hm_engine_t* e) {
 
 int hm_run(hm_engine_t* e) {
     if (!e) return HM_EINVAL;
-    if (!e->uploaded) return fail(e, HM_ESTATE, "hm_run: nothing uploaded");
+    hm_batch* b = legacy(e);
+    if (!b->uploaded) return fail(e, HM_ESTATE, "hm_run: nothing uploaded");
     try {
         HIP_TRY(hipSetDevice(e->device));
-        const int nc = (int)e->chunks.size();
-        {
-            Span sp(e, K_PREP, 0);
-            launch_prep(e->stream, e->d_raw.as<uint8_t>(), e->d_reads.as<ReadDesc>(), e->d_chunks.as<Chunk>(), nc,
-                        e->ctx_mask, e->d_bases.as<uint8_t>(), e->d_kin.as<uint32_t>(), e->d_counts.as<int32_t>(),
-                        e->d_err.as<int32_t>());
-            sp.end();
+        if (b->ran && !b->have_totals) {  // a re-run: fold the previous run's spans first
+            int rc = wait_totals(b);
+            if (rc < 0) return rc;
         }
-        {
-            Span sp(e, K_SCAN, 0);
-            launch_scan(e->stream, e->d_counts.as<int32_t>(), nc, e->d_offs.as<int32_t>(), e->d_totals.as<int32_t>());
-            sp.end();
-        }
-        {
-            Span sp(e, K_EMIT, 0);
-            launch_emit(e->stream, e->d_reads.as<ReadDesc>(), e->d_chunks.as<Chunk>(), nc, e->ctx_mask,
-                        e->d_bases.as<uint8_t>(), e->d_offs.as<int32_t>(), e->d_totals.as<int32_t>(),
-                        e->d_usites.as<USite>(), e->d_utag.as<uint8_t>(), e->d_csites.as<Site>());
-            sp.end();
-        }
-        HIP_TRY(hipGetLastError());
-        // the site counts size the CNN launches: one small D2H + sync per batch
-        HIP_TRY(hipMemcpyAsync(e->h_totals, e->d_totals.p, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        memcpy(e->totals, e->h_totals, sizeof e->totals);
-        ensure_site_buffers(e, e->totals[3]);
-        for (int c = 0; c < 3; ++c) {
-            if (!(e->ctx_mask >> c & 1) || e->totals[c] == 0) continue;
-            run_cnn(e, c, e->d_csites.as<Site>() + e->totals[4 + c], nullptr, e->totals[c], nullptr, 0);
-        }
-        HIP_TRY(hipMemcpyAsync(e->h_err, e->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-        e->ran = true;
-        e->synced = false;
+        enqueue_run(b);
     } catch (const HipErr& h) {
         return fail_hip(e, h);
     }
@@ -508,69 +697,48 @@ int hm_run(hm_engine_t* e) {
 
 int hm_sync(hm_engine_t* e) {
     if (!e) return HM_EINVAL;
+    hm_batch* b = legacy(e);
     try {
         HIP_TRY(hipSetDevice(e->device));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        collect_timing(e);
-        e->synced = true;
-        if (e->ran && *e->h_err) {
-            *e->h_err = 0;
-            HIP_TRY(hipMemset(e->d_err.p, 0, sizeof(int32_t)));
-            return fail(e, HM_EDATA, "illegal BAM base encoded value in a staged read");
+        if (!b->ran) {
+            if (b->uploaded) HIP_TRY(hipEventSynchronize(b->ev_in));
+            return HM_OK;
         }
+        return wait_totals(b);
     } catch (const HipErr& h) {
         return fail_hip(e, h);
     }
-    return HM_OK;
 }
 
 int64_t hm_num_sites(hm_engine_t* e, int ctx) {
     if (!e || ctx < 0 || ctx > 3) return HM_EINVAL;
-    if (!e->ran) return fail(e, HM_ESTATE, "hm_num_sites: hm_run first");
-    return e->totals[ctx];
+    hm_batch* b = legacy(e);
+    if (!b->ran) return fail(e, HM_ESTATE, "hm_num_sites: hm_run first");
+    try {
+        HIP_TRY(hipSetDevice(e->device));
+        int rc = wait_totals(b);
+        if (rc < 0) return rc;
+    } catch (const HipErr& h) {
+        return fail_hip(e, h);
+    }
+    return b->totals[ctx];
 }
 
 int64_t hm_fetch(hm_engine_t* e, hm_call_t* out, int64_t cap) {
     if (!e || (!out && cap > 0)) return HM_EINVAL;
-    if (!e->ran) return fail(e, HM_ESTATE, "hm_fetch: hm_run first");
-    int rc = hm_sync(e);
-    if (rc < 0) return rc;
-    const int64_t n = e->totals[3];
-    if (n > cap) return fail(e, HM_EINVAL, "hm_fetch: output capacity too small");
-    if (n == 0) return 0;
+    hm_batch* b = legacy(e);
+    if (!b->ran) return fail(e, HM_ESTATE, "hm_fetch: hm_run first");
     try {
-        std::vector<USite> us((size_t)n);
-        std::vector<uint8_t> tag((size_t)n), ml((size_t)n);
-        std::vector<float> p((size_t)n);
-        HIP_TRY(hipMemcpy(us.data(), e->d_usites.p, (size_t)n * sizeof(USite), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(tag.data(), e->d_utag.p, (size_t)n, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(ml.data(), e->d_ml.p, (size_t)n, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(p.data(), e->d_p.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-        // unified list is ordered by (read, qoff); per read emit FWD calls then REV calls, each by qoff
-        // (the order build_one_mod_bam consumes: mod_main.cpp:217-251)
-        int64_t o = 0, i = 0;
-        while (i < n) {
-            int64_t j = i;
-            while (j < n && us[(size_t)j].read_idx == us[(size_t)i].read_idx) ++j;
-            const int32_t rid = e->reads[(size_t)us[(size_t)i].read_idx].read_id;
-            for (int strand = 0; strand < 2; ++strand)
-                for (int64_t k = i; k < j; ++k) {
-                    if ((tag[(size_t)k] >> 2) != strand) continue;
-                    hm_call_t& c = out[o++];
-                    c.read_id = rid;
-                    c.qoff = us[(size_t)k].qoff;
-                    c.strand = (uint8_t)strand;
-                    c.ctx = tag[(size_t)k] & 3;
-                    c.scaled_prob = ml[(size_t)k];
-                    c.reserved = 0;
-                    c.p = p[(size_t)k];
-                }
-            i = j;
-        }
-        return o;
+        HIP_TRY(hipSetDevice(e->device));
+        int rc = fetch_calls(b);
+        if (rc < 0) return rc;
     } catch (const HipErr& h) {
         return fail_hip(e, h);
     }
+    const int64_t n = b->totals[3];
+    if (n > cap) return fail(e, HM_EINVAL, "hm_fetch: output capacity too small");
+    if (n) memcpy(out, b->h_calls.p, (size_t)n * sizeof(hm_call_t));
+    return n;
 }
 
 int hm_flush(hm_engine_t* e) {
@@ -584,21 +752,129 @@ int64_t hm_drain(hm_engine_t* e, hm_call_t* out, int64_t cap) {
     return n;
 }
 
+// ---- the asynchronous batch pipeline ---------------------------------------------------------------------------------
+hm_batch_t* hm_batch_begin(hm_engine_t* e) {
+    if (!e) return nullptr;
+    std::unique_lock<std::mutex> lk(e->mu);
+    for (;;) {
+        for (size_t i = 1; i < e->slots.size(); ++i)
+            if (e->slots[i]->state == hm_batch::FREE) {
+                hm_batch* b = e->slots[i].get();
+                b->state = hm_batch::STAGING;
+                reset_staging(b);
+                return b;
+            }
+        if ((int)e->slots.size() - 1 < e->max_slots) {
+            try {
+                HIP_TRY(hipSetDevice(e->device));
+                hm_batch* b = new_slot(e, (int)e->slots.size());
+                b->state = hm_batch::STAGING;
+                return b;
+            } catch (const HipErr& h) {
+                e->err = std::string("HIP error: ") + hipGetErrorString(h.code) + " at " + h.what;
+                return nullptr;
+            }
+        }
+        e->cv.wait(lk);  // every slot is staged or in flight: wait for an hm_batch_release
+    }
+}
+
+int hm_batch_submit_read(hm_batch_t* b, int32_t read_id, int32_t l_qseq, int32_t flag, const uint8_t* seq4, const void* fi,
+                         int fi_w, const void* fp, int fp_w, const void* ri, int ri_w, const void* rp, int rp_w) {
+    if (!b) return HM_EINVAL;
+    if (b->state != hm_batch::STAGING) return fail(b->e, HM_ESTATE, "hm_batch_submit_read: batch is not being staged");
+    return stage_read(b, read_id, l_qseq, flag, seq4, fi, fi_w, fp, fp_w, ri, ri_w, rp, rp_w);
+}
+
+int64_t hm_batch_staged_bases(const hm_batch_t* b) { return b ? b->total_bases : HM_EINVAL; }
+
+int hm_batch_enqueue(hm_batch_t* b) {
+    if (!b) return HM_EINVAL;
+    hm_engine* e = b->e;
+    if (b->state != hm_batch::STAGING) return fail(e, HM_ESTATE, "hm_batch_enqueue: batch is not being staged");
+    try {
+        HIP_TRY(hipSetDevice(e->device));
+        enqueue_upload(b);  // slot stream: independent of every other batch
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            b->state = hm_batch::QUEUED;
+        }
+        std::lock_guard<std::mutex> lk(e->order_mu);  // the compute stream takes batches in the order they are queued
+        enqueue_run(b);
+    } catch (const HipErr& h) {
+        return fail_hip(e, h);
+    }
+    return HM_OK;
+}
+
+int hm_batch_done(hm_batch_t* b) {
+    if (!b) return HM_EINVAL;
+    if (b->state != hm_batch::QUEUED) return fail(b->e, HM_ESTATE, "hm_batch_done: batch was not queued");
+    if (b->have_totals) return 1;
+    const hipError_t q = hipEventQuery(b->ev_out);
+    if (q == hipSuccess) return 1;
+    if (q == hipErrorNotReady) return 0;
+    return fail(b->e, HM_EDEVICE, std::string("HIP error: ") + hipGetErrorString(q));
+}
+
+int64_t hm_batch_wait(hm_batch_t* b, const hm_call_t** calls) {
+    if (!b) return HM_EINVAL;
+    hm_engine* e = b->e;
+    if (b->state != hm_batch::QUEUED) return fail(e, HM_ESTATE, "hm_batch_wait: batch was not queued");
+    try {
+        HIP_TRY(hipSetDevice(e->device));
+        int rc = calls ? fetch_calls(b) : wait_totals(b);
+        if (rc < 0) return rc;
+    } catch (const HipErr& h) {
+        return fail_hip(e, h);
+    }
+    if (calls) *calls = b->h_calls.p;
+    return b->totals[3];
+}
+
+int64_t hm_batch_num_sites(hm_batch_t* b, int ctx) {
+    if (!b || ctx < 0 || ctx > 3) return HM_EINVAL;
+    const int64_t rc = hm_batch_wait(b, nullptr);
+    return rc < 0 ? rc : b->totals[ctx];
+}
+
+int hm_batch_release(hm_batch_t* b) {
+    if (!b) return HM_EINVAL;
+    hm_engine* e = b->e;
+    if (b->state == hm_batch::QUEUED) {  // never hand a slot back while the device still works on it
+        (void)hipSetDevice(e->device);
+        (void)hipEventSynchronize(b->ev_out);
+        (void)hipStreamSynchronize(b->s_io);
+        try {
+            collect_timing(e, b->spans, b->h_totals);
+        } catch (const HipErr&) {
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        b->state = hm_batch::FREE;
+    }
+    e->cv.notify_all();
+    return HM_OK;
+}
+
+// ---- seams of the parity tests (operate on the synchronous batch) ---------------------------------------------------------
 int64_t hm_scan_sites(hm_engine_t* e, int ctx, int32_t* read_id, int32_t* qoff, uint8_t* strand, int64_t cap) {
     if (!e || ctx < 0 || ctx > 2) return HM_EINVAL;
-    if (!e->ran) return fail(e, HM_ESTATE, "hm_scan_sites: hm_run first");
+    hm_batch* b = legacy(e);
+    if (!b->ran) return fail(e, HM_ESTATE, "hm_scan_sites: hm_run first");
     int rc = hm_sync(e);
     if (rc < 0) return rc;
-    const int64_t n = e->totals[ctx];
+    const int64_t n = b->totals[ctx];
     if (n > cap) return fail(e, HM_EINVAL, "hm_scan_sites: output capacity too small");
     if (n == 0) return 0;
     try {
         std::vector<Site> s((size_t)n);
-        std::vector<uint8_t> tag((size_t)e->totals[3]);
-        HIP_TRY(hipMemcpy(s.data(), e->d_csites.as<Site>() + e->totals[4 + ctx], (size_t)n * sizeof(Site), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(tag.data(), e->d_utag.p, tag.size(), hipMemcpyDeviceToHost));
+        std::vector<uint8_t> tag((size_t)b->totals[3]);
+        HIP_TRY(hipMemcpy(s.data(), b->d_csites.as<Site>() + b->totals[4 + ctx], (size_t)n * sizeof(Site), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tag.data(), b->d_utag.p, tag.size(), hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < n; ++i) {
-            if (read_id) read_id[i] = e->reads[(size_t)s[(size_t)i].read_idx].read_id;
+            if (read_id) read_id[i] = b->reads.p[(size_t)s[(size_t)i].read_idx].read_id;
             if (qoff) qoff[i] = s[(size_t)i].qoff;
             if (strand) strand[i] = tag[(size_t)s[(size_t)i].uidx] >> 2;
         }
@@ -610,22 +886,26 @@ int64_t hm_scan_sites(hm_engine_t* e, int ctx, int32_t* read_id, int32_t* qoff, 
 
 int hm_windows(hm_engine_t* e, int ctx, int64_t first, int64_t n, float* out_host) {
     if (!e || ctx < 0 || ctx > 2 || first < 0 || n < 0) return HM_EINVAL;
-    if (!e->ran) return fail(e, HM_ESTATE, "hm_windows: hm_run first");
-    if (first + n > e->totals[ctx]) return fail(e, HM_EINVAL, "hm_windows: site range out of bounds");
+    hm_batch* b = legacy(e);
+    if (!b->ran) return fail(e, HM_ESTATE, "hm_windows: hm_run first");
+    int rc = hm_sync(e);
+    if (rc < 0) return rc;
+    if (first + n > b->totals[ctx]) return fail(e, HM_EINVAL, "hm_windows: site range out of bounds");
     if (n == 0) return HM_OK;
     try {
         HIP_TRY(hipSetDevice(e->device));
         const size_t bytes = (size_t)n * KMER * FEATS * sizeof(float);
         e->d_win.reserve(bytes);
-        Span sp(e, K_WINDOW, n);
-        launch_windows(e->stream, e->d_csites.as<Site>() + e->totals[4 + ctx] + first, (int)n, e->d_reads.as<ReadDesc>(),
-                       e->d_bases.as<uint8_t>(), e->d_kin.as<uint32_t>(), e->model[ctx].w.bn, e->d_win.as<float>(),
+        std::vector<TimedSpan> spans;
+        Span sp(e, &spans, K_WINDOW, 0, 0, n);
+        launch_windows(e->stream, b->d_csites.as<Site>() + b->totals[4 + ctx] + first, (int)n, b->d_reads.as<ReadDesc>(),
+                       b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), e->model[ctx].w.bn, e->d_win.as<float>(),
                        e->num_cu * 8);
         sp.end();
         HIP_TRY(hipGetLastError());
         if (out_host) HIP_TRY(hipMemcpyAsync(out_host, e->d_win.p, bytes, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
-        collect_timing(e);
+        collect_timing(e, spans, nullptr);
     } catch (const HipErr& h) {
         return fail_hip(e, h);
     }
@@ -640,15 +920,19 @@ int hm_cnn_logits(hm_engine_t* e, int ctx, const float* windows, int64_t n, floa
         HIP_TRY(hipSetDevice(e->device));
         const size_t bytes = (size_t)n * KMER * FEATS * sizeof(float);
         e->d_win.reserve(bytes);
-        ensure_site_buffers(e, n);
+        DevBuf d_lg, d_p, d_ml;  // results of this call only: the staged batch's buffers stay untouched
+        d_lg.reserve((size_t)n * 2 * sizeof(float));
+        d_p.reserve((size_t)n * sizeof(float));
+        d_ml.reserve((size_t)n);
+        struct Guard {
+            DevBuf &a, &b, &c;
+            ~Guard() { a.release(); b.release(); c.release(); }
+        } guard{d_lg, d_p, d_ml};
         HIP_TRY(hipMemcpyAsync(e->d_win.p, windows, bytes, hipMemcpyHostToDevice, e->stream));
-        run_cnn(e, ctx, nullptr, e->d_win.as<float>(), n, nullptr, 0);
-        if (logits) HIP_TRY(hipMemcpyAsync(logits, e->d_logits.p, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-        if (p) HIP_TRY(hipMemcpyAsync(p, e->d_p.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-        if (ml) HIP_TRY(hipMemcpyAsync(ml, e->d_ml.p, (size_t)n, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        collect_timing(e);
-        e->ran = false;  // result buffers no longer hold the staged batch's calls
+        run_cnn_windows(e, ctx, e->d_win.as<float>(), n, d_lg.as<float>(), d_p.as<float>(), d_ml.as<uint8_t>(), nullptr, 0);
+        if (logits) HIP_TRY(hipMemcpy(logits, d_lg.p, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost));
+        if (p) HIP_TRY(hipMemcpy(p, d_p.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        if (ml) HIP_TRY(hipMemcpy(ml, d_ml.p, (size_t)n, hipMemcpyDeviceToHost));
     } catch (const HipErr& h) {
         return fail_hip(e, h);
     }
@@ -669,15 +953,18 @@ int64_t hm_debug_layer(hm_engine_t* e, int ctx, const float* window, int layer, 
         const size_t bytes = (size_t)KMER * FEATS * sizeof(float);
         e->d_win.reserve(bytes);
         e->d_dbg.reserve((size_t)nf * sizeof(float));
-        ensure_site_buffers(e, 1);
+        DevBuf res;  // logits / p / ml of the one window
+        res.reserve(64);
+        struct Guard {
+            DevBuf& a;
+            ~Guard() { a.release(); }
+        } guard{res};
         HIP_TRY(hipMemcpyAsync(e->d_win.p, window, bytes, hipMemcpyHostToDevice, e->stream));
-        run_cnn(e, ctx, nullptr, e->d_win.as<float>(), 1, e->d_dbg.as<float>(), layer);
+        run_cnn_windows(e, ctx, e->d_win.as<float>(), 1, res.as<float>(), res.as<float>() + 2,
+                        reinterpret_cast<uint8_t*>(res.as<float>() + 3), e->d_dbg.as<float>(), layer);
         // conv4 is the front->tail hand-off and already sits in HBM
         const void* src = layer == 4 ? e->d_act4.p : e->d_dbg.p;
-        HIP_TRY(hipMemcpyAsync(out, src, (size_t)nf * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        collect_timing(e);
-        e->ran = false;
+        HIP_TRY(hipMemcpy(out, src, (size_t)nf * sizeof(float), hipMemcpyDeviceToHost));
     } catch (const HipErr& h) {
         return fail_hip(e, h);
     }
@@ -704,12 +991,14 @@ int hm_get_stamps(hm_engine_t* e, uint64_t* out, int cap) {
 
 int hm_get_timing(hm_engine_t* e, hm_timing_t* t) {
     if (!e || !t) return HM_EINVAL;
+    std::lock_guard<std::mutex> lk(e->mu);
     *t = e->acc;
     return HM_OK;
 }
 
 int hm_reset_timing(hm_engine_t* e) {
     if (!e) return HM_EINVAL;
+    std::lock_guard<std::mutex> lk(e->mu);
     memset(&e->acc, 0, sizeof e->acc);
     return HM_OK;
 }

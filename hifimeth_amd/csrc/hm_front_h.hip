@@ -378,7 +378,7 @@ __device__ __forceinline__ void dump_planes(const half_t* hi, const half_t* lo, 
 }
 
 template <int K1, bool RAW, bool STAMP = false, bool W16 = false>
-__global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ sites, int n_sites,
+__global__ __launch_bounds__(512) void front_kernel_h(SiteRange sr,
                                                        const ReadDesc* __restrict__ reads,
                                                        const uint8_t* __restrict__ bases,
                                                        const uint32_t* __restrict__ kin,
@@ -386,6 +386,8 @@ __global__ __launch_bounds__(512) void front_kernel_h(const Site* __restrict__ s
                                                        float* __restrict__ act4, float* __restrict__ dbg, int dbg_layer,
                                                        unsigned long long* __restrict__ stamps) {
     using G = GeoH<K1>;
+    const Site* sites;
+    const int n_sites = resolve_sites(sr, sites);
     unsigned long long tacc[N_STAMP];
     unsigned long long tprev = 0;
     if (STAMP) {
@@ -669,12 +671,14 @@ __device__ __forceinline__ void zero_pad_rows_h(half_t* hi, half_t* lo, int rs, 
 }
 
 template <bool W16>
-__global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ act4, int n_sites, CtxWeights W,
-                                                      const Site* __restrict__ sites, float* __restrict__ logits,
+__global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ act4, SiteRange sr, CtxWeights W,
+                                                      float* __restrict__ logits,
                                                       float* __restrict__ prob, uint8_t* __restrict__ ml,
                                                       float* __restrict__ dbg, int dbg_layer) {
     using T = TailGeoH;
     constexpr int S = T::S, NW = 8;
+    const Site* sites;
+    const int n_sites = resolve_sites(sr, sites);
     __shared__ __attribute__((aligned(16))) half_t smem[T::LDS_HALVES];
     half_t* h0 = smem;
     half_t* l0 = smem + T::P0;
@@ -797,36 +801,39 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
     }
 }
 
-void launch_tail_h(hipStream_t st, const float* act4, int n, const CtxWeights& w, const Site* sites, float* logits,
-                   float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer, bool w16) {
-    if (n <= 0) return;
-    const int groups = (n + TAIL_SITES - 1) / TAIL_SITES;
-    if (w16)
-        hipLaunchKernelGGL(tail_kernel_h<true>, dim3(min(groups, grid)), dim3(512), 0, st, act4, n, w, sites, logits, p, ml,
-                           dbg, dbg_layer);
-    else
-        hipLaunchKernelGGL(tail_kernel_h<false>, dim3(min(groups, grid)), dim3(512), 0, st, act4, n, w, sites, logits, p, ml,
-                           dbg, dbg_layer);
+static int cnn_grid_h(const SiteRange& sr, int per_group, int grid) {
+    if (sr.totals) return grid;
+    return max(1, min((sr.cap + per_group - 1) / per_group, grid));
 }
 
-void launch_front_h(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
+void launch_tail_h(hipStream_t st, const float* act4, const SiteRange& sr, const CtxWeights& w, float* logits,
+                   float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer, bool w16) {
+    if (sr.cap <= 0) return;
+    const dim3 g(cnn_grid_h(sr, TAIL_SITES, grid));
+    if (w16)
+        hipLaunchKernelGGL(tail_kernel_h<true>, g, dim3(512), 0, st, act4, sr, w, logits, p, ml, dbg, dbg_layer);
+    else
+        hipLaunchKernelGGL(tail_kernel_h<false>, g, dim3(512), 0, st, act4, sr, w, logits, p, ml, dbg, dbg_layer);
+}
+
+void launch_front_h(hipStream_t st, int k1, const SiteRange& sr, const ReadDesc* reads, const uint8_t* bases,
                     const uint32_t* kin, const float* windows, const CtxWeights& w, float* act4, int grid, float* dbg,
                     int dbg_layer, unsigned long long* stamps, bool w16) {
-    if (n <= 0) return;
-    const dim3 g(min(n, grid)), b(512);
+    if (sr.cap <= 0) return;
+    const dim3 g(cnn_grid_h(sr, 1, grid)), b(512);
     const bool raw = windows == nullptr;
     if (w16) {  // fp16-weights mode (conv1 and fc1 keep split weights): BASELINE.json configs[4]
         if (k1 == 11) {
-            if (raw) hipLaunchKernelGGL((front_kernel_h<11, true, false, true>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
-            else hipLaunchKernelGGL((front_kernel_h<11, false, false, true>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
+            if (raw) hipLaunchKernelGGL((front_kernel_h<11, true, false, true>), g, b, 0, st, sr, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
+            else hipLaunchKernelGGL((front_kernel_h<11, false, false, true>), g, b, 0, st, sr, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
         } else {
-            if (raw) hipLaunchKernelGGL((front_kernel_h<13, true, false, true>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
-            else hipLaunchKernelGGL((front_kernel_h<13, false, false, true>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
+            if (raw) hipLaunchKernelGGL((front_kernel_h<13, true, false, true>), g, b, 0, st, sr, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
+            else hipLaunchKernelGGL((front_kernel_h<13, false, false, true>), g, b, 0, st, sr, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
         }
         return;
     }
-#define HM_FRONT_H(K1, RAW, ST)                                                                                       \
-    hipLaunchKernelGGL((front_kernel_h<K1, RAW, ST>), g, b, 0, st, sites, n, reads, bases, kin, windows, w, act4, dbg, \
+#define HM_FRONT_H(K1, RAW, ST)                                                                                  \
+    hipLaunchKernelGGL((front_kernel_h<K1, RAW, ST>), g, b, 0, st, sr, reads, bases, kin, windows, w, act4, dbg, \
                        dbg_layer, stamps)
     if (stamps && raw) {
         if (k1 == 11) HM_FRONT_H(11, true, true); else HM_FRONT_H(13, true, true);

@@ -9,14 +9,20 @@ namespace hm {
 // feature extraction -------------------------------------------------------------------------
 // A: decode 4-bit bases to forward-strand codes, pack the four kinetics arrays per forward
 //    position, count sites per 1024-base chunk.
+//    sctx[j] = context of the site at forward position j (CTX_NONE = 3: no site, or its context is masked out).
 void launch_prep(hipStream_t st, const uint8_t* raw, const ReadDesc* reads, const Chunk* chunks, int n_chunks,
-                 int ctx_mask, uint8_t* bases, uint32_t* kin, int32_t* chunk_counts, int32_t* err);
-// S: exclusive scan of the chunk counts -> chunk offsets, totals[4] (CpG, CHG, CHH, all), ctx_base[3].
+                 int ctx_mask, uint8_t* bases, uint32_t* kin, uint8_t* sctx, int32_t* chunk_counts, int32_t* err);
+// S: exclusive scan of the NCNT chunk counters -> chunk offsets [n_chunks + 1][NCNT] (last row = totals),
+//    totals[8]: CpG, CHG, CHH, all, ctx_base[3], reverse-strand sites.
 void launch_scan(hipStream_t st, const int32_t* chunk_counts, int n_chunks, int32_t* chunk_offs, int32_t* totals);
-// B: emit the unified (read, qoff)-ordered site list and the per-context lists.
+// B: emit the unified (read, qoff)-ordered site list, the per-context lists and opos[uidx] = position of the site's
+//    call in the output order (per read: forward-strand calls by qoff, then reverse-strand calls; mod_main.cpp:217-251).
 void launch_emit(hipStream_t st, const ReadDesc* reads, const Chunk* chunks, int n_chunks, int ctx_mask,
                  const uint8_t* bases, const int32_t* chunk_offs, const int32_t* totals, USite* usites,
-                 uint8_t* utag, Site* csites);
+                 uint8_t* utag, Site* csites, int32_t* opos);
+// P: results -> packed hm_call_t records in output order (one D2H then carries a batch's results).
+void launch_pack(hipStream_t st, const USite* usites, const uint8_t* utag, const int32_t* opos, const float* prob,
+                 const uint8_t* ml, const ReadDesc* reads, const int32_t* totals, void* calls, int grid);
 // W: materialise raw (no bn0) 401x8 fp32 windows for a site list: out[n][401][8].
 void launch_windows(hipStream_t st, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
                     const uint32_t* kin, const BnTables* bn, float* out, int grid);
@@ -24,20 +30,35 @@ void launch_windows(hipStream_t st, const Site* sites, int n, const ReadDesc* re
 // CNN ------------------------------------------------------------------------------------------
 // front: window (from staged reads, or from materialised windows when `windows` != nullptr)
 //        -> bn0 -> conv1..conv4 -> act4[n][25][96]
-void launch_front(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
+//        The sites of a launch are named by a SiteRange (hm_device.h): counts stay on the device.
+void launch_front(hipStream_t st, int k1, const SiteRange& sr, const ReadDesc* reads, const uint8_t* bases,
                   const uint32_t* kin, const float* windows, const CtxWeights& w, float* act4, int grid,
                   float* dbg, int dbg_layer, int waves, unsigned long long* stamps);
 int front_stamp_slots();
 // split-half (f16x3) variant of the front kernel: fp16 hi/lo operands on v_mfma_f32_16x16x32_f16, fp32 accumulate
-void launch_front_h(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
+void launch_front_h(hipStream_t st, int k1, const SiteRange& sr, const ReadDesc* reads, const uint8_t* bases,
                     const uint32_t* kin, const float* windows, const CtxWeights& w, float* act4, int grid, float* dbg,
                     int dbg_layer, unsigned long long* stamps, bool w16);
-void launch_tail_h(hipStream_t st, const float* act4, int n, const CtxWeights& w, const Site* sites, float* logits,
+void launch_tail_h(hipStream_t st, const float* act4, const SiteRange& sr, const CtxWeights& w, float* logits,
                    float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer, bool w16);
 // tail: conv5..conv8, fc1, fc2, softmax for 8 sites per workgroup pass.
 // results go to index sites[i].uidx (or i when sites == nullptr).
-void launch_tail(hipStream_t st, const float* act4, int n, const CtxWeights& w, const Site* sites, float* logits,
+void launch_tail(hipStream_t st, const float* act4, const SiteRange& sr, const CtxWeights& w, float* logits,
                  float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer);
+
+#ifdef __HIPCC__
+// sites and count of a launch, resolved on the device (see SiteRange)
+__device__ __forceinline__ int resolve_sites(const SiteRange& sr, const Site*& sites) {
+    if (!sr.totals) {
+        sites = sr.base;
+        return sr.cap;
+    }
+    int n = sr.totals[sr.ctx] - sr.off;
+    n = n < 0 ? 0 : (n > sr.cap ? sr.cap : n);
+    sites = sr.base + sr.totals[4 + sr.ctx] + sr.off;
+    return n;
+}
+#endif
 
 size_t front_lds_bytes(int k1);
 size_t tail_lds_bytes();

@@ -93,9 +93,10 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const uint8_t* __res
                                                               const Chunk* __restrict__ chunks, int ctx_mask,
                                                               uint8_t* __restrict__ bases,
                                                               uint32_t* __restrict__ kin,
+                                                              uint8_t* __restrict__ sctx,
                                                               int32_t* __restrict__ chunk_counts,
                                                               int32_t* __restrict__ err) {
-    __shared__ int cnt[4];
+    __shared__ int cnt[4];  // CpG, CHG, CHH, reverse-strand sites
     const Chunk ch = chunks[blockIdx.x];
     const ReadDesc rd = reads[ch.read_idx];
     if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
@@ -105,9 +106,9 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const uint8_t* __res
     int c[PER_THREAD + 4];
 #pragma unroll
     for (int t = 0; t < PER_THREAD + 4; ++t) c[t] = fwd_code(raw, rd, j0 - 2 + t, bad);
-    int my[3] = {0, 0, 0};
+    int my[4] = {0, 0, 0, 0};
     if (j0 < rd.len) {
-        uint32_t bpack = 0;
+        uint32_t bpack = 0, cpack = 0;
         uint32_t kq[PER_THREAD];
 #pragma unroll
         for (int t = 0; t < PER_THREAD; ++t) {
@@ -120,19 +121,28 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const uint8_t* __res
                 const int jr = rd.len - 1 - j;
                 kq[t] = kin_code(raw, rd.off_fi, rd.w[0], j) | (kin_code(raw, rd.off_fp, rd.w[1], j) << 8) |
                         (kin_code(raw, rd.off_ri, rd.w[2], jr) << 16) | (kin_code(raw, rd.off_rp, rd.w[3], jr) << 24);
-                const int cls = classify(c[t], c[t + 1], c[t + 2], c[t + 3], c[t + 4]);
-                if (cls != CTX_NONE && ((ctx_mask >> cls) & 1)) ++my[cls];
+                int cls = classify(c[t], c[t + 1], c[t + 2], c[t + 3], c[t + 4]);
+                if (cls != CTX_NONE && !((ctx_mask >> cls) & 1)) cls = CTX_NONE;
+                if (cls != CTX_NONE) {
+                    ++my[cls];
+                    if (c[t + 2] == 2) ++my[3];  // forward G: the cytosine sits on the reverse strand
+                }
+                cpack |= (uint32_t)cls << (8 * t);
+            } else {
+                cpack |= (uint32_t)CTX_NONE << (8 * t);
             }
         }
         const int64_t g = rd.base_off + j0;  // base_off and chunk starts are multiples of 4
         if (j0 + PER_THREAD <= rd.len) {
             *reinterpret_cast<uint32_t*>(bases + g) = bpack;
+            *reinterpret_cast<uint32_t*>(sctx + g) = cpack;
             *reinterpret_cast<uint4*>(kin + g) = make_uint4(kq[0], kq[1], kq[2], kq[3]);
         } else {
 #pragma unroll
             for (int t = 0; t < PER_THREAD; ++t)
                 if (j0 + t < rd.len) {
                     bases[g + t] = (uint8_t)c[t + 2];
+                    sctx[g + t] = (uint8_t)(cpack >> (8 * t));
                     kin[g + t] = kq[t];
                 }
         }
@@ -140,50 +150,57 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const uint8_t* __res
     if (my[0]) atomicAdd(&cnt[0], my[0]);
     if (my[1]) atomicAdd(&cnt[1], my[1]);
     if (my[2]) atomicAdd(&cnt[2], my[2]);
+    if (my[3]) atomicAdd(&cnt[3], my[3]);
     if (bad) atomicOr(err, 1);
     __syncthreads();
-    if (threadIdx.x < 4) {
-        const int v = threadIdx.x < 3 ? cnt[threadIdx.x] : cnt[0] + cnt[1] + cnt[2];
-        chunk_counts[4 * blockIdx.x + threadIdx.x] = v;
+    if (threadIdx.x < NCNT) {
+        const int t = threadIdx.x;
+        const int v = t < 3 ? cnt[t] : t == 3 ? cnt[0] + cnt[1] + cnt[2] : cnt[3];
+        chunk_counts[NCNT * blockIdx.x + t] = v;
     }
 }
 
-// single-workgroup exclusive scan of the 4 per-chunk counters
+// single-workgroup exclusive scan of the NCNT per-chunk counters; row n_chunks of `offs` holds the totals (the emit
+// kernel reads "first chunk of the next read" there for the last read)
 constexpr int SCAN_THREADS = 1024;
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const int32_t* __restrict__ counts, int n_chunks,
                                                              int32_t* __restrict__ offs,
                                                              int32_t* __restrict__ totals) {
-    __shared__ int part[4][SCAN_THREADS];
+    __shared__ int part[NCNT][SCAN_THREADS];
     const int per = (n_chunks + SCAN_THREADS - 1) / SCAN_THREADS;
-    const int lo = threadIdx.x * per, hi = min(n_chunks, lo + per);
-    int s[4] = {0, 0, 0, 0};
+    const int lo = min(n_chunks, (int)threadIdx.x * per), hi = min(n_chunks, lo + per);
+    int s[NCNT];
+#pragma unroll
+    for (int c = 0; c < NCNT; ++c) s[c] = 0;
     for (int i = lo; i < hi; ++i)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s[c] += counts[4 * i + c];
+        for (int c = 0; c < NCNT; ++c) s[c] += counts[NCNT * i + c];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) part[c][threadIdx.x] = s[c];
+    for (int c = 0; c < NCNT; ++c) part[c][threadIdx.x] = s[c];
     __syncthreads();
     // Hillis-Steele inclusive scan over the 1024 partials
     for (int d = 1; d < SCAN_THREADS; d <<= 1) {
-        int v[4];
+        int v[NCNT];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = threadIdx.x >= d ? part[c][threadIdx.x - d] : 0;
+        for (int c = 0; c < NCNT; ++c) v[c] = threadIdx.x >= d ? part[c][threadIdx.x - d] : 0;
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 4; ++c) part[c][threadIdx.x] += v[c];
+        for (int c = 0; c < NCNT; ++c) part[c][threadIdx.x] += v[c];
         __syncthreads();
     }
-    int run[4];
+    int run[NCNT];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) run[c] = part[c][threadIdx.x] - s[c];  // exclusive prefix of this thread's range
+    for (int c = 0; c < NCNT; ++c) run[c] = part[c][threadIdx.x] - s[c];  // exclusive prefix of this thread's range
     for (int i = lo; i < hi; ++i)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            offs[4 * i + c] = run[c];
-            run[c] += counts[4 * i + c];
+        for (int c = 0; c < NCNT; ++c) {
+            offs[NCNT * i + c] = run[c];
+            run[c] += counts[NCNT * i + c];
         }
     if (threadIdx.x == SCAN_THREADS - 1) {
         const int t0 = part[0][threadIdx.x], t1 = part[1][threadIdx.x], t2 = part[2][threadIdx.x];
+#pragma unroll
+        for (int c = 0; c < NCNT; ++c) offs[NCNT * n_chunks + c] = part[c][threadIdx.x];
         totals[0] = t0;
         totals[1] = t1;
         totals[2] = t2;
@@ -191,6 +208,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const int32_t* __res
         totals[4] = 0;        // ctx_base: the three context lists are laid out back to back
         totals[5] = t0;
         totals[6] = t0 + t1;
+        totals[7] = part[4][threadIdx.x];  // reverse-strand sites
     }
 }
 
@@ -211,8 +229,8 @@ __global__ __launch_bounds__(PREP_THREADS) void emit_kernel(const ReadDesc* __re
                                                               const int32_t* __restrict__ chunk_offs,
                                                               const int32_t* __restrict__ totals,
                                                               USite* __restrict__ usites, uint8_t* __restrict__ utag,
-                                                              Site* __restrict__ csites) {
-    __shared__ int wave_tot[3][PREP_THREADS / 64];
+                                                              Site* __restrict__ csites, int32_t* __restrict__ opos) {
+    __shared__ int wave_tot[4][PREP_THREADS / 64];
     const Chunk ch = chunks[blockIdx.x];
     const ReadDesc rd = reads[ch.read_idx];
     const int j0 = ch.start + PER_THREAD * threadIdx.x;
@@ -223,7 +241,7 @@ __global__ __launch_bounds__(PREP_THREADS) void emit_kernel(const ReadDesc* __re
         c[t] = (j >= 0 && j < rd.len) ? bases[rd.base_off + j] : 4;
     }
     int cls[PER_THREAD];
-    int my[3] = {0, 0, 0};
+    int my[4] = {0, 0, 0, 0};  // CpG, CHG, CHH, reverse-strand sites
 #pragma unroll
     for (int t = 0; t < PER_THREAD; ++t) {
         int k = CTX_NONE;
@@ -232,30 +250,40 @@ __global__ __launch_bounds__(PREP_THREADS) void emit_kernel(const ReadDesc* __re
             if (k != CTX_NONE && !((ctx_mask >> k) & 1)) k = CTX_NONE;
         }
         cls[t] = k;
-        if (k != CTX_NONE) ++my[k];
+        if (k != CTX_NONE) {
+            ++my[k];
+            if (c[t + 2] == 2) ++my[3];
+        }
     }
     // wavefront-level scans, then a 4-wave carry through LDS
-    int incl[3];
+    int incl[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         incl[k] = wave_incl_scan(my[k]);
         if (lane == 63) wave_tot[k][wave] = incl[k];
     }
     __syncthreads();
+    const int32_t* co = chunk_offs + NCNT * blockIdx.x;
     int rank[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         int carry = 0;
         for (int w = 0; w < wave; ++w) carry += wave_tot[k][w];
-        rank[k] = chunk_offs[4 * blockIdx.x + k] + carry + incl[k] - my[k];
+        rank[k] = co[k] + carry + incl[k] - my[k];
     }
+    // Output order of the calls (mod_main.cpp:217-251): per read the forward-strand calls by qoff, then the
+    // reverse-strand ones.  A read's chunks are consecutive, so its range in the unified list and its number of
+    // reverse-strand sites follow from the scanned counters of its first chunk and of the chunk after its last.
+    const int k0 = blockIdx.x - ch.start / CHUNK, k1 = k0 + (rd.len + CHUNK - 1) / CHUNK;
+    const int read_first = chunk_offs[NCNT * k0 + 3], rev0 = chunk_offs[NCNT * k0 + 4];
+    const int n_fwd = (chunk_offs[NCNT * k1 + 3] - read_first) - (chunk_offs[NCNT * k1 + 4] - rev0);
+    int rev_before = co[4] - rev0 + incl[3] - my[3];  // reverse-strand sites of this read in front of this thread's
+    for (int w = 0; w < wave; ++w) rev_before += wave_tot[3][w];
     // rank in the unified list: sites of all contexts in position order. chunk_offs[..][3] was
     // scanned from the per-chunk sum, thread-local order is position order, so the unified rank is
     // the chunk's unified offset plus the number of sites (any context) before this one in the chunk.
-    const int ubase = chunk_offs[4 * blockIdx.x + 3];
-    int urank = ubase + (rank[0] - chunk_offs[4 * blockIdx.x + 0]) + (rank[1] - chunk_offs[4 * blockIdx.x + 1]) +
-                (rank[2] - chunk_offs[4 * blockIdx.x + 2]);
+    int urank = co[3] + (rank[0] - co[0]) + (rank[1] - co[1]) + (rank[2] - co[2]);
 #pragma unroll
     for (int t = 0; t < PER_THREAD; ++t) {
         const int k = cls[t];
@@ -265,8 +293,25 @@ __global__ __launch_bounds__(PREP_THREADS) void emit_kernel(const ReadDesc* __re
         usites[urank] = USite{ch.read_idx, q};
         utag[urank] = (uint8_t)(k | (strand << 2));
         csites[totals[4 + k] + rank[k]] = Site{ch.read_idx, q, urank};
+        opos[urank] = strand ? read_first + n_fwd + rev_before : read_first + (urank - read_first - rev_before);
+        rev_before += strand;
         ++rank[k];
         ++urank;
+    }
+}
+
+// results -> hm_call_t records in output order: one 16-byte store per site into the packed array that the engine
+// copies to the host with a single D2H (layout of hm_call_t: include/hifimeth_hip.h)
+__global__ __launch_bounds__(256) void pack_kernel(const USite* __restrict__ usites, const uint8_t* __restrict__ utag,
+                                                    const int32_t* __restrict__ opos, const float* __restrict__ prob,
+                                                    const uint8_t* __restrict__ ml, const ReadDesc* __restrict__ reads,
+                                                    const int32_t* __restrict__ totals, uint4* __restrict__ calls) {
+    const int n = totals[3];
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) {
+        const USite us = usites[u];
+        const uint32_t tag = utag[u];
+        const uint32_t word = (tag >> 2) | ((tag & 3u) << 8) | ((uint32_t)ml[u] << 16);  // strand, ctx, scaled_prob, reserved
+        calls[opos[u]] = make_uint4((uint32_t)reads[us.read_idx].read_id, (uint32_t)us.qoff, word, __float_as_uint(prob[u]));
     }
 }
 
@@ -577,7 +622,7 @@ struct Geo {
 };
 
 template <int K1, bool RAW, int NW, bool STAMP = false>
-__global__ __launch_bounds__(NW * 64) void front_kernel(const Site* __restrict__ sites, int n_sites,
+__global__ __launch_bounds__(NW * 64) void front_kernel(SiteRange sr,
                                                      const ReadDesc* __restrict__ reads,
                                                      const uint8_t* __restrict__ bases,
                                                      const uint32_t* __restrict__ kin,
@@ -585,6 +630,8 @@ __global__ __launch_bounds__(NW * 64) void front_kernel(const Site* __restrict__
                                                      float* __restrict__ act4, float* __restrict__ dbg, int dbg_layer,
                                                      unsigned long long* __restrict__ stamps) {
     using G = Geo<K1>;
+    const Site* sites;
+    const int n_sites = resolve_sites(sr, sites);
     __shared__ __attribute__((aligned(16))) float smem[G::LDS_FLOATS];
     float* bufA = smem;
     float* bufB = smem + G::BUFA;
@@ -728,12 +775,14 @@ struct TailGeo {
     static constexpr int LDS_FLOATS = BUF0 + BUF1;
 };
 
-__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ act4, int n_sites, CtxWeights W,
-                                                    const Site* __restrict__ sites, float* __restrict__ logits,
+__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ act4, SiteRange sr, CtxWeights W,
+                                                    float* __restrict__ logits,
                                                     float* __restrict__ prob, uint8_t* __restrict__ ml,
                                                     float* __restrict__ dbg, int dbg_layer) {
     using T = TailGeo;
     constexpr int S = T::S;
+    const Site* sites;
+    const int n_sites = resolve_sites(sr, sites);
     __shared__ __attribute__((aligned(16))) float smem[T::LDS_FLOATS];
     float* buf0 = smem;
     float* buf1 = smem + T::BUF0;
@@ -821,10 +870,10 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ act
 // launchers
 // =================================================================================================
 void launch_prep(hipStream_t st, const uint8_t* raw, const ReadDesc* reads, const Chunk* chunks, int n_chunks,
-                 int ctx_mask, uint8_t* bases, uint32_t* kin, int32_t* chunk_counts, int32_t* err) {
+                 int ctx_mask, uint8_t* bases, uint32_t* kin, uint8_t* sctx, int32_t* chunk_counts, int32_t* err) {
     if (n_chunks <= 0) return;
     hipLaunchKernelGGL(prep_kernel, dim3(n_chunks), dim3(PREP_THREADS), 0, st, raw, reads, chunks, ctx_mask, bases, kin,
-                       chunk_counts, err);
+                       sctx, chunk_counts, err);
 }
 
 void launch_scan(hipStream_t st, const int32_t* chunk_counts, int n_chunks, int32_t* chunk_offs, int32_t* totals) {
@@ -833,10 +882,16 @@ void launch_scan(hipStream_t st, const int32_t* chunk_counts, int n_chunks, int3
 
 void launch_emit(hipStream_t st, const ReadDesc* reads, const Chunk* chunks, int n_chunks, int ctx_mask,
                  const uint8_t* bases, const int32_t* chunk_offs, const int32_t* totals, USite* usites,
-                 uint8_t* utag, Site* csites) {
+                 uint8_t* utag, Site* csites, int32_t* opos) {
     if (n_chunks <= 0) return;
     hipLaunchKernelGGL(emit_kernel, dim3(n_chunks), dim3(PREP_THREADS), 0, st, reads, chunks, ctx_mask, bases,
-                       chunk_offs, totals, usites, utag, csites);
+                       chunk_offs, totals, usites, utag, csites, opos);
+}
+
+void launch_pack(hipStream_t st, const USite* usites, const uint8_t* utag, const int32_t* opos, const float* prob,
+                 const uint8_t* ml, const ReadDesc* reads, const int32_t* totals, void* calls, int grid) {
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, st, usites, utag, opos, prob, ml, reads, totals,
+                       reinterpret_cast<uint4*>(calls));
 }
 
 void launch_windows(hipStream_t st, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
@@ -847,15 +902,21 @@ void launch_windows(hipStream_t st, const Site* sites, int n, const ReadDesc* re
                        bases, kin, bn, out);
 }
 
-void launch_front(hipStream_t st, int k1, const Site* sites, int n, const ReadDesc* reads, const uint8_t* bases,
+// number of workgroups of a persistent CNN launch: the site count is only known exactly when it is given directly
+static int cnn_grid(const SiteRange& sr, int per_group, int grid) {
+    if (sr.totals) return grid;
+    return std::max(1, std::min((sr.cap + per_group - 1) / per_group, grid));
+}
+
+void launch_front(hipStream_t st, int k1, const SiteRange& sr, const ReadDesc* reads, const uint8_t* bases,
                   const uint32_t* kin, const float* windows, const CtxWeights& w, float* act4, int grid, float* dbg,
                   int dbg_layer, int waves, unsigned long long* stamps) {
-    if (n <= 0) return;
-    const dim3 g(min(n, grid));
+    if (sr.cap <= 0) return;
+    const dim3 g(cnn_grid(sr, 1, grid));
     const bool raw = windows == nullptr;
-#define HM_FRONT(K1, RAW, NW, ST)                                                                                     \
-    hipLaunchKernelGGL((front_kernel<K1, RAW, NW, ST>), g, dim3(NW * 64), 0, st, sites, n, reads, bases, kin, windows, \
-                       w, act4, dbg, dbg_layer, stamps)
+#define HM_FRONT(K1, RAW, NW, ST)                                                                                  \
+    hipLaunchKernelGGL((front_kernel<K1, RAW, NW, ST>), g, dim3(NW * 64), 0, st, sr, reads, bases, kin, windows, w, \
+                       act4, dbg, dbg_layer, stamps)
     if (stamps && raw && waves == 8) {  // diagnostic build of the production configuration
         if (k1 == 11) HM_FRONT(11, true, 8, true); else HM_FRONT(13, true, 8, true);
     } else if (waves == 8) {
@@ -870,11 +931,10 @@ void launch_front(hipStream_t st, int k1, const Site* sites, int n, const ReadDe
 
 int front_stamp_slots() { return N_STAMP; }
 
-void launch_tail(hipStream_t st, const float* act4, int n, const CtxWeights& w, const Site* sites, float* logits,
+void launch_tail(hipStream_t st, const float* act4, const SiteRange& sr, const CtxWeights& w, float* logits,
                  float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer) {
-    if (n <= 0) return;
-    const int groups = (n + TAIL_SITES - 1) / TAIL_SITES;
-    hipLaunchKernelGGL(tail_kernel, dim3(min(groups, grid)), dim3(256), 0, st, act4, n, w, sites, logits, p, ml, dbg,
+    if (sr.cap <= 0) return;
+    hipLaunchKernelGGL(tail_kernel, dim3(cnn_grid(sr, TAIL_SITES, grid)), dim3(256), 0, st, act4, sr, w, logits, p, ml, dbg,
                        dbg_layer);
 }
 

@@ -17,7 +17,15 @@
  *
  * Plain pointers and sizes only; every call returns >= 0 on success and a negative HM_E* code
  * on failure (the reference abort()s instead: src/corelib/hbn_aux.hpp:100-104), with the message
- * available from hm_last_error().  An engine is driven by one host thread at a time.
+ * available from hm_last_error().
+ *
+ * Two ways to drive an engine:
+ *  - the synchronous calls (hm_submit_read ... hm_fetch): ONE implicit batch, one host thread; what the parity tests use;
+ *  - the batch pipeline (hm_batch_*): N slots per engine, each with pinned staging memory and its own copy stream.
+ *    Staging of different batches may run on different host threads (the reference's workers pull reads from a shared
+ *    queue: src/corelib/sam_batch.hpp:38-54); hm_batch_enqueue queues H2D -> scanner -> CNN -> results and returns
+ *    without any host/device synchronisation, so batch k+1 is staged and uploaded while batch k computes (the pinned
+ *    non-blocking staging of the reference's GPU variant, src/app-gpu/hifimeth-gpu/5mc_call_gpu.cpp:309-334,367).
  */
 #ifndef HIFIMETH_HIP_H
 #define HIFIMETH_HIP_H
@@ -64,6 +72,11 @@ typedef struct {
     int64_t front_launches[3], tail_launches[3];
     int64_t front_sites[3]; /* sites processed by the timed front launches */
     int64_t window_sites;
+    double pack_ms, empty_ms; /* result packing; CNN launches whose window of the site list turned out empty */
+    int64_t pack_launches, empty_launches;
+    double trunk_ms[3], edge_ms[3]; /* dense trunk (conv1..conv4 over whole reads) and window-edge kernels */
+    int64_t trunk_launches[3], edge_launches[3];
+    int64_t trunk_positions[3]; /* (read, strand view) positions evaluated by the timed trunk launches */
 } hm_timing_t;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
@@ -73,7 +86,7 @@ typedef struct {
 int hm_create(hm_engine_t** out, const char* model_dir, int ctx_mask, int device);
 void hm_destroy(hm_engine_t* e);
 const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a failed hm_create */
-/* options: "min_read_size" (-l, default 1000), "timing" (0/1), "sub_batch_sites" (front/tail
+/* options: "slots" (batches in flight of the hm_batch_* pipeline, default 3), "min_read_size" (-l, default 1000), "timing" (0/1), "sub_batch_sites" (front/tail
  * launch granularity, default 65536), "front_waves" (4 or 8 waves per front workgroup), "precision" (0 = fp32 MFMA, exact;
  * 1 = split-half fp16x3 MFMA with fp32 accumulate; 2 = fp16 WEIGHTS for conv2..conv8 (conv1 and fc1 keep split
  * weights), activations still split, fp32 accumulate: BASELINE.json configs[4], bar |dp| <= 1e-3), "stamps" (diagnostic) */
@@ -101,6 +114,26 @@ int64_t hm_fetch(hm_engine_t* e, hm_call_t* out, int64_t cap);
 /* convenience: hm_flush = hm_upload + hm_run ; hm_drain = hm_sync + hm_fetch + hm_clear */
 int hm_flush(hm_engine_t* e);
 int64_t hm_drain(hm_engine_t* e, hm_call_t* out, int64_t cap);
+
+/* ---- the asynchronous batch pipeline -------------------------------------------------------- */
+typedef struct hm_batch hm_batch_t;
+/* A free slot in STAGING state; blocks while all "slots" are staged or in flight.  NULL on error. */
+hm_batch_t* hm_batch_begin(hm_engine_t* e);
+/* hm_submit_read into this batch's pinned slab; batches may be staged concurrently from different threads */
+int hm_batch_submit_read(hm_batch_t* b, int32_t read_id, int32_t l_qseq, int32_t flag, const uint8_t* seq4,
+                         const void* fi, int fi_width, const void* fp, int fp_width, const void* ri, int ri_width,
+                         const void* rp, int rp_width);
+int64_t hm_batch_staged_bases(const hm_batch_t* b);
+/* Queues the batch: async H2D on the slot's stream, scanner + CNN + result packing on the engine's compute stream (site
+ * counts are consumed on the device), async D2H of the totals.  Returns at once; batches compute in queueing order. */
+int hm_batch_enqueue(hm_batch_t* b);
+int hm_batch_done(hm_batch_t* b); /* 1 finished, 0 still in flight, < 0 error; never blocks */
+/* Waits for THIS batch only.  Returns its number of calls; with calls != NULL also brings them to the host with one
+ * packed D2H and points *calls at them (pinned memory owned by the slot, valid until hm_batch_release), ordered by
+ * (read submission order, strand, qoff) like hm_fetch.  HM_EDATA if a staged read held an illegal base. */
+int64_t hm_batch_wait(hm_batch_t* b, const hm_call_t** calls);
+int64_t hm_batch_num_sites(hm_batch_t* b, int ctx); /* waits like hm_batch_wait(b, NULL) */
+int hm_batch_release(hm_batch_t* b); /* the slot may be handed out again */
 
 /* ---- seams used by the parity tests and the feature-extraction roofline ------------------- */
 /* extract_*_samples: site list of one context after hm_run, in (read, qoff) order */

@@ -423,3 +423,47 @@ def test_extreme_kinetics_and_homopolymers(mc, oracle, oracle_models):
     n, nml, worst = _check_calls(calls, reads, oracle, oracle_models, 7)
     assert n > 5000
     print(f"extreme kinetics: {n} sites, max|dp|={worst:.2e}")
+
+
+def test_batch_pipeline_matches_synchronous_calls(mc):
+    """The asynchronous batch pipeline (hm_batch_*: staging of slab k+1 overlapping the compute of slab k, site counts
+    consumed on the device, one packed D2H) returns byte-identical records to the synchronous calls."""
+    slabs = [synth_reads(n, seed=900 + i, gc=0.36 + 0.02 * i) for i, n in enumerate((9, 1, 14, 6, 11, 3))]
+    want = [mc.call(s).copy() for s in slabs]
+    got = []
+    total = mc.stream(slabs, on_batch=lambda k, b, calls: got.append((calls.copy(), [b.num_sites(c) for c in range(4)])))
+    assert total == sum(len(w) for w in want) and len(got) == len(slabs)
+    for w, (g, ns) in zip(want, got):
+        assert len(w) > 0 and w.tobytes() == g.tobytes()
+        assert ns[3] == len(w) and sum(ns[:3]) == ns[3] and [int((w["ctx"] == c).sum()) for c in range(3)] == ns[:3]
+
+
+def test_batches_staged_from_several_threads(mc):
+    """Different batches may be staged by different host threads (the reference's workers pull from a shared queue,
+    sam_batch.hpp:38-54); an empty batch and a batch of skipped reads go through the pipeline too."""
+    import threading
+    slabs = [synth_reads(7, seed=950 + i) for i in range(6)] + [[], synth_reads(4, seed=99, min_len=200, max_len=900)]
+    want = [mc.call(s).copy() for s in slabs]
+    got = [None] * len(slabs)
+    errs = []
+
+    def worker(ids):
+        try:
+            for i in ids:
+                b = mc.begin_batch()
+                b.submit_all(slabs[i])
+                b.enqueue()
+                got[i] = b.wait().copy()
+                b.release()
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    ts = [threading.Thread(target=worker, args=(range(k, len(slabs), 3),)) for k in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for w, g in zip(want, got):
+        assert w.tobytes() == g.tobytes()
+    assert len(want[-1]) == 0 and len(want[-2]) == 0
