@@ -243,27 +243,52 @@ def main():
             mc.set_option("precision", args.precision)
 
     if rank == 0:
-        front_ms = sum(tm["front_ms"])
-        front_launches = sum(tm["front_launches"])
-        flop_front = sum(2.0 * MAC_FRONT[c] * tm["front_sites"][c] for c in range(3))
-        achieved = flop_front / (front_ms * 1e-3) / 1e12 if front_ms > 0 else 0.0
-        # executed fp16 products per algorithmic MAC: 3 (hi*hi, hi*lo, lo*hi), except conv1, whose operand is exact fp16
-        # since bn0 is folded into its weights: 2 (1 stacked product over a doubled K)
         split = args.precision >= 1
-        exec_macs = sum((3.0 * MAC_FRONT[c] - CONV1_MAC[c]) * tm["front_sites"][c] for c in range(3)) if split else 0.0
-        products = exec_macs / max(1.0, sum(MAC_FRONT[c] * tm["front_sites"][c] for c in range(3))) if split else 1.0
         peak = PEAK_FP16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
-        roof = {"bound": "mfma", "unit": "TFLOP/s", "achieved": achieved, "peak": peak, "frac": achieved / peak,
-                "avg_launch_ms": front_ms / front_launches if front_launches else None, "launches": front_launches,
-                "traffic": None,
-                "traffic_note": "HBM bytes need separate rocprofv3 --pmc passes; see profiles/ for the per-launch figures",
-                "kernel": ("front_kernel_h (window+bn0+conv1..conv4, v_mfma_f32_16x16x32_f16 x3 split-half, fp32 accumulate)"
-                           if split else "front_kernel (window+bn0+conv1..conv4, v_mfma_f32_16x16x4_f32)")}
-        if split:
-            roof.update(executed=products * achieved, frac_executed=products * achieved / peak, products_per_mac=products,
-                        vs_fp32_mfma_peak=achieved / PEAK_FP32_MFMA_TFLOPS)
+        front_ms = sum(tm["front_ms"])
+        trunk_ms = sum(tm["trunk_ms"])
+        flop_front_sites = lambda n: sum(2.0 * MAC_FRONT[c] * n[c] for c in range(3))  # noqa: E731
+        if trunk_ms > 0:
+            # Dominant kernel: trunk_kernel (conv1..conv4 once per read position instead of once per site).
+            # `achieved` prices it with the ALGORITHMIC work of the path: the conv1..conv4 FLOPs the
+            # reference spends on the sites this kernel served; `executed` counts the MFMA work it really issued
+            # (16 384 FLOP per v_mfma_f32_16x16x32_f16; per 112-position tile 9 / 9 / 8 / 7 position tiles of 16 rows, conv1
+            # one stacked product over 6 | 7 k-blocks, conv2..conv4 three split-half products over 12 k-blocks).
+            launches = sum(tm["trunk_launches"])
+            achieved = flop_front_sites(sites_ctx) / (trunk_ms * 1e-3) / 1e12
+            mfma_tile = {0: 9 * 6 * 8 + (9 + 8) * 36 * 8 + 7 * 36 * 6, 2: 9 * 7 * 8 + (9 + 8) * 36 * 8 + 7 * 36 * 6}
+            mfma_tile[1] = mfma_tile[0]
+            executed = sum(tm["trunk_positions"][c] / 112.0 * mfma_tile[c] * 16384.0 for c in range(3)) / (trunk_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "unit": "TFLOP/s", "achieved": achieved, "peak": peak, "frac": achieved / peak,
+                    "avg_launch_ms": trunk_ms / launches, "launches": launches,
+                    "executed": executed, "frac_executed": executed / peak,
+                    "algorithmic_flops_per_site": {"CpG": 2 * MAC_FRONT[0], "CHG": 2 * MAC_FRONT[1], "CHH": 2 * MAC_FRONT[2]},
+                    "positions_per_site": sum(tm["trunk_positions"]) / max(1, sites_job),
+                    "traffic": None,
+                    "traffic_note": "HBM bytes need separate rocprofv3 --pmc passes; see profiles/ for the per-launch figures",
+                    "kernel": "trunk_kernel (feature rows + bn0 + conv1..conv4 as dense a-trous maps over every read position, "
+                              "v_mfma_f32_16x16x32_f16 split-half x3, fp32 accumulate); `achieved` = the reference's conv1..conv4 "
+                              "FLOPs for the sites served / kernel time, `executed` = MFMA FLOPs issued / kernel time"}
+        else:
+            front_launches = sum(tm["front_launches"])
+            achieved = flop_front_sites(tm["front_sites"]) / (front_ms * 1e-3) / 1e12 if front_ms > 0 else 0.0
+            # executed fp16 products per algorithmic MAC: 3 (hi*hi, hi*lo, lo*hi), except conv1, whose operand is exact
+            # fp16 since bn0 is folded into its weights: 2 (1 stacked product over a doubled K)
+            exec_macs = sum((3.0 * MAC_FRONT[c] - CONV1_MAC[c]) * tm["front_sites"][c] for c in range(3)) if split else 0.0
+            products = exec_macs / max(1.0, sum(MAC_FRONT[c] * tm["front_sites"][c] for c in range(3))) if split else 1.0
+            roof = {"bound": "mfma", "unit": "TFLOP/s", "achieved": achieved, "peak": peak, "frac": achieved / peak,
+                    "avg_launch_ms": front_ms / front_launches if front_launches else None, "launches": front_launches,
+                    "traffic": None,
+                    "traffic_note": "HBM bytes need separate rocprofv3 --pmc passes; see profiles/ for the per-launch figures",
+                    "kernel": ("front_kernel_h (window+bn0+conv1..conv4 per site, v_mfma_f32_16x16x32_f16 x3 split-half, fp32 accumulate)"
+                               if split else "front_kernel (window+bn0+conv1..conv4 per site, v_mfma_f32_16x16x4_f32)")}
+            if split:
+                roof.update(executed=products * achieved, frac_executed=products * achieved / peak, products_per_mac=products,
+                            vs_fp32_mfma_peak=achieved / PEAK_FP32_MFMA_TFLOPS)
         gpu_ms = {k: tm[k] for k in ("prep_ms", "scan_ms", "emit_ms", "pack_ms", "empty_ms")}
         gpu_ms["front_ms"] = front_ms
+        gpu_ms["trunk_ms"] = trunk_ms
+        gpu_ms["edge_ms"] = sum(tm["edge_ms"])
         gpu_ms["tail_ms"] = sum(tm["tail_ms"])
         gpu_ms["empty_launches"] = tm["empty_launches"]
         out = {
@@ -278,6 +303,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {0: "f32", 1: "f16x3+f32acc", 2: "f16w/f16x2+f32acc"}[args.precision],
+            "cnn_path": "dense trunk (conv1..conv4 once per read position) + per-site edge rows + tail" if trunk_ms > 0
+                        else "per site (front + tail kernels)",
             "data": "synthetic",
             "config": {"workload": f"streamed: every step stages a fresh slab of {args.reads} synthetic HiFi reads (GC 0.36, ~15 kb "
                                    "log-normal, codev1 kinetics; BASELINE.json configs[2] statistics, all three contexts) through "

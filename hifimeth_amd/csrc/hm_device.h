@@ -51,6 +51,39 @@ struct SiteRange {
     const Site* base;       // the three per-context lists back to back
     const int32_t* totals;  // [0..2] sites per context, [3] all, [4..6] first element of each context's list
     int32_t ctx, off, cap;
+    // optional sub-range [*lo, *hi) of the context's list: the sites of one read group (the scanned per-chunk counters
+    // at the group's first chunk and at the first chunk behind it); nullptr = the whole list
+    const int32_t* lo;
+    const int32_t* hi;
+};
+
+// ---- dense trunk (hm_trunk.hip) ---------------------------------------------------------------------------------------
+// conv1..conv4 of the model are evaluated ONCE per (read, strand view) position instead of once per site: with stride-2
+// convolutions the activations of a site's window are samples of four dense "a trous" maps over the read,
+//     c1[p] = E1[off - 201 + 2p]   c2[q] = E2[off - 203 + 4q]   c3[r] = E3[off - 207 + 8r]   c4[s] = E4[off - 215 + 16s]
+//     E1[x] = relu(b1 + sum_t W1[t] X[x + t]),  E(l)[x] = relu(b + sum_t W[t] E(l-1)[x + t * 2^(l-1)])
+// for every output that touches neither the window's zero padding nor another such output: all but the first and the
+// last position of every layer.  `off` is the site's position in its strand view (forward: qoff; reverse: L-1-qoff, the
+// read seen as its reverse complement with the strands' kinetics swapped), X the bn0-normalised feature rows (rows
+// outside the read are bn0(0), exactly what the reference's zero-filled window rows become: eval_kmer_features.cpp:36-40).
+struct RInfo {
+    int64_t base_off;  // first element of the read in bases / kin / sctx
+    int32_t len;
+    int32_t map_off;   // row of view position -200 of this read in the group's maps
+};
+
+struct TrunkTile {
+    int32_t read_idx;
+    int32_t u0;        // first view position the tile owns (the first tile of a read starts at -200)
+};
+
+constexpr int TR_OWN = 112;   // view positions per tile
+constexpr int TR_PAD = 200;   // the maps cover view positions [-200, len + 200)
+
+struct TrunkMaps {
+    uint16_t* e[3];     // E1..E3: [2 views][rows][hi 128 | lo 128] fp16 halves (only the rows an edge chain reads are written)
+    float* e4;          // E4: [2 views][rows][96] fp32
+    int64_t view_rows;  // rows per view
 };
 
 // bn0 folded into lookup tables, computed on the host with the ONNX BatchNormalization

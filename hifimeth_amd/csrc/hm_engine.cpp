@@ -89,7 +89,7 @@ struct PinnedArr {
     }
 };
 
-enum Kind { K_PREP, K_SCAN, K_EMIT, K_PACK, K_WINDOW, K_FRONT, K_TAIL };
+enum Kind { K_PREP, K_SCAN, K_EMIT, K_PACK, K_WINDOW, K_FRONT, K_TAIL, K_TRUNK, K_EDGE, K_TAILG };
 
 struct TimedSpan {
     int kind, ctx;
@@ -119,10 +119,17 @@ struct hm_batch {
     PinnedArr<uint8_t> slab;
     PinnedArr<ReadDesc> reads;
     PinnedArr<Chunk> chunks;
+    PinnedArr<RInfo> rinfo;      // dense trunk: per read
+    PinnedArr<TrunkTile> tiles;  // dense trunk: 112-position tiles of every read, in read order
+    struct Group {               // consecutive reads whose maps share one set of buffers
+        int chunk_lo, chunk_hi, tile_lo, tile_hi;
+        int64_t bases, rows;
+    };
+    std::vector<Group> groups;
     int64_t total_bases = 0;  // padded to a multiple of 4 per read
 
     // device
-    DevBuf d_raw, d_reads, d_chunks, d_bases, d_kin, d_sctx, d_counts, d_offs, d_totals, d_err;
+    DevBuf d_raw, d_reads, d_chunks, d_rinfo, d_tiles, d_bases, d_kin, d_sctx, d_counts, d_offs, d_totals, d_err;
     DevBuf d_usites, d_utag, d_csites, d_opos, d_logits, d_p, d_ml, d_calls;
     int32_t* h_totals = nullptr;  // pinned [8]
     int32_t* h_err = nullptr;     // pinned
@@ -141,6 +148,8 @@ struct hm_engine {
     int front_waves = 8;
     int precision = 1;  // 1 = split-half f16x3 MFMA with fp32 accumulate (default), 0 = fp32 MFMA
     int max_slots = 3;  // batch slots of the asynchronous API (the legacy calls use one more, slot 0)
+    int trunk = 1;      // 1 = conv1..conv4 once per read position (hm_trunk.hip), 0 = once per site (front kernels)
+    int64_t group_bases = int64_t(2) << 20;  // reads per trunk group: their maps take ~3.9 KB per base
     bool stamps_on = false;
     std::vector<unsigned long long> stamp_sum;
     bool timing = false;
@@ -155,6 +164,7 @@ struct hm_engine {
 
     // scratch shared by all batches: only touched by kernels on the compute stream, which runs batches in order
     DevBuf d_act4, d_win, d_dbg, d_stamps;
+    DevBuf d_map[3], d_e4, d_edge4, d_e4row;  // dense trunk: maps of one read group, edge rows of its sites
 
     std::vector<hipEvent_t> pool;
     hm_timing_t acc{};
@@ -228,6 +238,9 @@ void collect_timing(hm_engine* e, std::vector<TimedSpan>& spans, const int32_t* 
         case K_EMIT: t.emit_ms += ms; ++t.emit_launches; break;
         case K_PACK: t.pack_ms += ms; ++t.pack_launches; break;
         case K_WINDOW: t.window_ms += ms; ++t.window_launches; t.window_sites += s.cap; break;
+        case K_TRUNK: t.trunk_ms[s.ctx] += ms; ++t.trunk_launches[s.ctx]; t.trunk_positions[s.ctx] += s.cap; break;
+        case K_EDGE: t.edge_ms[s.ctx] += ms; ++t.edge_launches[s.ctx]; break;
+        case K_TAILG: t.tail_ms[s.ctx] += ms; ++t.tail_launches[s.ctx]; break;
         case K_FRONT:
             if (n > 0) { t.front_ms[s.ctx] += ms; ++t.front_launches[s.ctx]; t.front_sites[s.ctx] += n; }
             else { t.empty_ms += ms; ++t.empty_launches; }
@@ -352,13 +365,15 @@ hm_batch* new_slot(hm_engine* e, int id) {
 
 void free_slot(hm_batch* b) {
     if (b->s_io) (void)hipStreamSynchronize(b->s_io);
-    for (DevBuf* d : {&b->d_raw, &b->d_reads, &b->d_chunks, &b->d_bases, &b->d_kin, &b->d_sctx, &b->d_counts, &b->d_offs,
+    for (DevBuf* d : {&b->d_raw, &b->d_reads, &b->d_chunks, &b->d_rinfo, &b->d_tiles, &b->d_bases, &b->d_kin, &b->d_sctx, &b->d_counts, &b->d_offs,
                       &b->d_totals, &b->d_err, &b->d_usites, &b->d_utag, &b->d_csites, &b->d_opos, &b->d_logits, &b->d_p,
                       &b->d_ml, &b->d_calls})
         d->release();
     b->slab.release();
     b->reads.release();
     b->chunks.release();
+    b->rinfo.release();
+    b->tiles.release();
     b->h_calls.release();
     if (b->h_totals) (void)hipHostFree(b->h_totals);
     if (b->h_err) (void)hipHostFree(b->h_err);
@@ -375,6 +390,9 @@ void reset_staging(hm_batch* b) {
     b->slab.n = 0;
     b->reads.n = 0;
     b->chunks.n = 0;
+    b->rinfo.n = 0;
+    b->tiles.n = 0;
+    b->groups.clear();
     b->total_bases = 0;
     b->uploaded = b->ran = b->have_totals = b->have_calls = false;
     memset(b->totals, 0, sizeof b->totals);
@@ -417,8 +435,20 @@ int stage_read(hm_batch* b, int32_t read_id, int32_t l_qseq, int32_t flag, const
         rd.read_id = read_id;
         for (int k = 0; k < 4; ++k) rd.w[k] = (uint8_t)w[k];
         const int ridx = (int)b->reads.n;
+        // dense trunk: the read's maps cover view positions [-200, L + 200) in tiles of TR_OWN; a new group starts when
+        // the current one holds group_bases
+        if (b->groups.empty() || b->groups.back().bases >= e->group_bases)
+            b->groups.push_back(hm_batch::Group{(int)b->chunks.n, (int)b->chunks.n, (int)b->tiles.n, (int)b->tiles.n, 0, 0});
+        hm_batch::Group& g = b->groups.back();
+        const int ntile = (l_qseq + 2 * TR_PAD + TR_OWN - 1) / TR_OWN;
+        b->rinfo.push_back(RInfo{b->total_bases, l_qseq, (int32_t)g.rows});
+        for (int t = 0; t < ntile; ++t) b->tiles.push_back(TrunkTile{ridx, -TR_PAD + t * TR_OWN});
         b->reads.push_back(rd);
         for (int st = 0; st < l_qseq; st += CHUNK) b->chunks.push_back(Chunk{ridx, st});
+        g.rows += (int64_t)ntile * TR_OWN;
+        g.bases += l_qseq;
+        g.chunk_hi = (int)b->chunks.n;
+        g.tile_hi = (int)b->tiles.n;
         b->total_bases += (int64_t)((L + 3) & ~size_t(3));
     } catch (const HipErr& h) {
         return fail_hip(e, h);
@@ -450,9 +480,61 @@ void enqueue_upload(hm_batch* b) {
     if (b->slab.n) HIP_TRY(hipMemcpyAsync(b->d_raw.p, b->slab.p, b->slab.n, hipMemcpyHostToDevice, b->s_io));
     if (nr) HIP_TRY(hipMemcpyAsync(b->d_reads.p, b->reads.p, nr * sizeof(ReadDesc), hipMemcpyHostToDevice, b->s_io));
     if (nc) HIP_TRY(hipMemcpyAsync(b->d_chunks.p, b->chunks.p, nc * sizeof(Chunk), hipMemcpyHostToDevice, b->s_io));
+    b->d_rinfo.reserve(std::max<size_t>(nr, 1) * sizeof(RInfo));
+    b->d_tiles.reserve(std::max<size_t>(b->tiles.n, 1) * sizeof(TrunkTile));
+    if (nr) HIP_TRY(hipMemcpyAsync(b->d_rinfo.p, b->rinfo.p, nr * sizeof(RInfo), hipMemcpyHostToDevice, b->s_io));
+    if (b->tiles.n) HIP_TRY(hipMemcpyAsync(b->d_tiles.p, b->tiles.p, b->tiles.n * sizeof(TrunkTile), hipMemcpyHostToDevice, b->s_io));
     HIP_TRY(hipEventRecord(b->ev_in, b->s_io));
     b->uploaded = true;
     b->ran = b->have_totals = b->have_calls = false;
+}
+
+// Dense trunk path: per read group and context  trunk (conv1..conv4 once per view position) -> edge (the two conv4 rows
+// per site that are not samples of the maps) -> tail (gathers its conv4 rows).  Every launch is sized by host-known
+// quantities (tiles) or reads its site range from the scanned chunk counters on the device.
+void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans) {
+    hm_engine* e = b->e;
+    int64_t max_rows = 1, max_bases = 1;
+    for (const auto& g : b->groups) {
+        max_rows = std::max(max_rows, g.rows);
+        max_bases = std::max(max_bases, g.bases);
+    }
+    for (int i = 0; i < 3; ++i) e->d_map[i].reserve((size_t)max_rows * 2 * 256 * sizeof(uint16_t));
+    e->d_e4.reserve((size_t)max_rows * 2 * C4_CH * sizeof(float));
+    e->d_edge4.reserve((size_t)max_bases * 2 * C4_CH * sizeof(float));
+    e->d_e4row.reserve((size_t)max_bases * sizeof(int32_t));
+    const bool w16 = e->precision == 2;
+    const int32_t* offs = b->d_offs.as<int32_t>();
+    for (const auto& g : b->groups) {
+        const TrunkMaps maps{{e->d_map[0].as<uint16_t>(), e->d_map[1].as<uint16_t>(), e->d_map[2].as<uint16_t>()},
+                             e->d_e4.as<float>(), g.rows};
+        const int n_tiles = g.tile_hi - g.tile_lo;
+        for (int c = 0; c < 3; ++c) {
+            if (!(e->ctx_mask >> c & 1)) continue;
+            const DeviceModel& dm = e->model[c];
+            const int n_views = c == CHH ? 2 : 1;  // CpG / CHG are called on the forward strand only (eval_kmer_features.cpp:89-126)
+            {
+                Span sp(e, spans, K_TRUNK, c, 0, (int64_t)n_tiles * TR_OWN * n_views);
+                launch_trunk(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
+                             b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->num_cu, w16);
+                sp.end();
+            }
+            const SiteRange sr{b->d_csites.as<Site>(), b->d_totals.as<int32_t>(), c, 0, (int32_t)std::min<int64_t>(g.bases, INT32_MAX),
+                               offs + (size_t)NCNT * g.chunk_lo + c, offs + (size_t)NCNT * g.chunk_hi + c};
+            {
+                Span sp(e, spans, K_EDGE, c);
+                launch_edge(e->stream, dm.k1, sr, b->d_rinfo.as<RInfo>(), b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), dm.w,
+                            maps, e->d_edge4.as<float>(), e->d_e4row.as<int32_t>(), e->num_cu, w16);
+                sp.end();
+            }
+            {
+                Span sp(e, spans, K_TAILG, c);
+                launch_tail_gather(e->stream, sr, dm.w, maps, e->d_edge4.as<float>(), e->d_e4row.as<int32_t>(),
+                                   b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu, w16);
+                sp.end();
+            }
+        }
+    }
 }
 
 // scanner + CNN + pack on the compute stream, then the totals' D2H on the slot stream; returns without waiting
@@ -480,6 +562,9 @@ void enqueue_run(hm_batch* b) {
                     b->d_csites.as<Site>(), b->d_opos.as<int32_t>());
         sp.end();
     }
+    if (e->trunk && e->precision >= 1) {
+        run_trunk_path(b, spans);
+    } else {
     // The CNN launches cover [0, bound) of every context's list in windows of `sb` sites; how many sites a window
     // really holds is resolved on the device.  bound = staged bases (a position carries at most one site); the
     // window grows with the batch so that a batch never needs more than ~48 launch pairs per context.
@@ -496,8 +581,10 @@ void enqueue_run(hm_batch* b) {
                             nullptr, 0);
         }
     }
+    }
     {
         Span sp(e, spans, K_PACK);
+        const int64_t bound = nc ? b->total_bases : 0;
         const int grid = (int)std::clamp<int64_t>((bound / 3 + 255) / 256, 1, (int64_t)e->num_cu * 8);
         launch_pack(e->stream, b->d_usites.as<USite>(), b->d_utag.as<uint8_t>(), b->d_opos.as<int32_t>(), b->d_p.as<float>(),
                     b->d_ml.as<uint8_t>(), b->d_reads.as<ReadDesc>(), b->d_totals.as<int32_t>(), b->d_calls.p, grid);
@@ -602,7 +689,9 @@ void hm_destroy(hm_engine_t* e) {
     for (auto& b : e->slots) free_slot(b.get());
     e->slots.clear();
     for (auto& m : e->model) m.params.release();
-    for (DevBuf* b : {&e->d_act4, &e->d_win, &e->d_dbg, &e->d_stamps}) b->release();
+    for (DevBuf* b : {&e->d_act4, &e->d_win, &e->d_dbg, &e->d_stamps, &e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4,
+                      &e->d_edge4, &e->d_e4row})
+        b->release();
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -636,6 +725,11 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
     } else if (k == "sub_batch_sites") {
         if (value < TAIL_SITES) return fail(e, HM_EINVAL, "sub_batch_sites too small");
         e->sub_batch = value / TAIL_SITES * TAIL_SITES;
+    } else if (k == "trunk") {
+        e->trunk = value != 0;
+    } else if (k == "group_bases") {
+        if (value < 1) return fail(e, HM_EINVAL, "group_bases must be positive");
+        e->group_bases = value;
     } else if (k == "slots") {
         if (value < 1 || value > 16) return fail(e, HM_EINVAL, "slots must be 1..16");
         e->max_slots = (int)value;

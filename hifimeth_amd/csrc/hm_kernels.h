@@ -53,12 +53,25 @@ __device__ __forceinline__ int resolve_sites(const SiteRange& sr, const Site*& s
         sites = sr.base;
         return sr.cap;
     }
-    int n = sr.totals[sr.ctx] - sr.off;
+    const int first = sr.lo ? *sr.lo : 0, last = sr.hi ? *sr.hi : sr.totals[sr.ctx];
+    int n = last - first - sr.off;
     n = n < 0 ? 0 : (n > sr.cap ? sr.cap : n);
-    sites = sr.base + sr.totals[4 + sr.ctx] + sr.off;
+    sites = sr.base + sr.totals[4 + sr.ctx] + first + sr.off;
     return n;
 }
 #endif
+
+// dense trunk path (hm_trunk.hip): conv1..conv4 once per (read, strand view) position, the two window-edge rows of
+// conv4 per site, then the tail gathers its conv4 rows from the maps
+void launch_trunk(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
+                  const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,
+                  const TrunkMaps& maps, int grid, bool w16);
+void launch_edge(hipStream_t st, int k1, const SiteRange& sr, const RInfo* rinfo, const uint8_t* bases,
+                 const uint32_t* kin, const CtxWeights& w, const TrunkMaps& maps, float* edge4, int32_t* e4row, int grid,
+                 bool w16);
+void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const float* edge4,
+                        const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, bool w16);
+size_t trunk_lds_bytes();
 
 size_t front_lds_bytes(int k1);
 size_t tail_lds_bytes();

@@ -1,0 +1,387 @@
+// hm_trunk.hip -- the dense trunk: conv1..conv4 of the CNN evaluated once per (read, strand view) POSITION.
+//
+// The reference runs the whole network on every site's 401-row window (mod_batch.cpp:66-75).  Neighbouring sites of a
+// read are a few bases apart, so their windows are the same rows shifted, and with stride-2 convolutions the
+// activations of a window are SAMPLES of dense maps over the read (hm_device.h, "dense trunk"):
+//     c1[p] = E1[off - 201 + 2p]   c2[q] = E2[off - 203 + 4q]   c3[r] = E3[off - 207 + 8r]   c4[s] = E4[off - 215 + 16s]
+// with E(l) the layer evaluated at EVERY position with its taps 2^(l-1) rows apart (dilation instead of stride).  This
+// holds for every output position except the first and the last of each layer (they see the window's zero padding, or
+// the neighbour that does).  So per strand view a read needs each layer once per base -- 146 k MAC per position -- instead
+// of 197 / 99 / 50 / 25 positions per site: ~5x fewer MACs at the site density of an all-context run, with identical
+// products (same weights, same inputs, fp32 accumulation; only the summation order inside the MFMA differs).
+//
+//   trunk_kernel : one workgroup per tile of 112 view positions: feature rows -> E1 -> E2 -> E3 in LDS (split fp16
+//                  planes, a-trous implicit GEMM on v_mfma_f32_16x16x32_f16, M = 144 / 144 / 128 / 112 rows: no ragged
+//                  tiles) -> E4 to HBM; the E1..E3 rows that some site's edge chain needs are written out as well.
+//   edge_kernel  : the first and last conv4 row of every site (the only two that are not samples of E4): per side a
+//                  chain of four one-row layers over rows gathered from the maps, 32 sites stacked along M.
+//   The tail kernel (hm_front_h.hip, GATHER) then picks a site's 23 interior conv4 rows out of E4 + its two edge rows.
+//
+// Reference for what is computed: training/model_cnn.py:8-85 / models/*.onnx (mod_main.cpp:32-98).
+#include "hm_convh.h"
+
+namespace hm {
+
+namespace {
+
+constexpr int TR_M1 = 144, TR_M2 = 144, TR_M3 = 128, TR_M4 = TR_OWN;  // rows computed per layer (needed: 140 / 136 / 128 / 112)
+constexpr int TR_XROWS = 160;  // feature rows of a tile: 144 + K1 - 1 <= 156
+constexpr int TR_RS = 136;     // halves per LDS row: 128 channels + 16 B pad (conflict-free ds_read_b128 at row stride 1)
+constexpr int TR_WRS = 8;      // feature row = 8 exact halves
+constexpr int TR_AROWS = 148, TR_BROWS = 144;
+static_assert(TR_M1 + 4 <= TR_AROWS && TR_M3 + 8 <= TR_BROWS && TR_M4 + 16 <= TR_M3, "halo plan");
+constexpr int TR_LDS_HALVES = 2 * TR_AROWS * TR_RS + 2 * TR_BROWS * TR_RS;
+
+// ReLU + split -> LDS planes (row m, no padding rows: the dense form has none); the rows an edge chain will read also
+// go to the HBM map as [hi 128 | lo 128]
+template <int BIT>
+struct EpiTrunk {
+    half_t* hi;
+    half_t* lo;
+    const float* __restrict__ bias;
+    const uint8_t* flags;
+    half_t* __restrict__ g;  // map row of tile row 0
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        half4 h, l;
+        split4(acc, h, l);
+        *reinterpret_cast<half4*>(hi + m * TR_RS + col) = h;
+        *reinterpret_cast<half4*>(lo + m * TR_RS + col) = l;
+        if (m < TR_OWN && ((flags[m] >> BIT) & 1)) {
+            *reinterpret_cast<half4*>(g + (size_t)m * 256 + col) = h;
+            *reinterpret_cast<half4*>(g + (size_t)m * 256 + 128 + col) = l;
+        }
+    }
+};
+
+struct EpiE4 {
+    float* __restrict__ g;
+    const float* __restrict__ bias;
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        *reinterpret_cast<float4*>(g + (size_t)m * C4_CH + col) =
+            make_float4(relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3]));
+    }
+};
+
+// feature row of view position x of a read: 8 EXACT halves (one-hot base, decoded frame counts / 32; bn0 lives in conv1's
+// folded weights, hm_weights.cpp); all zeros outside the read
+__device__ __forceinline__ uint4 feature_row(int b, uint32_t k, int view) {
+    uint4 row = make_uint4(0u, 0u, 0u, 0u);
+    if (b < 0) return row;
+    if (view) {  // the read seen from its reverse strand: complemented base, the strands' kinetics swapped
+        if (b < 4) b = 3 - b;
+        k = (k >> 16) | (k << 16);
+    }
+    row.x = b == 0 ? 0x3c00u : b == 1 ? 0x3c000000u : 0u;
+    row.y = b == 2 ? 0x3c00u : b == 3 ? 0x3c000000u : 0u;
+    // codev1 byte t -> frames = (((t & 63) + 64) << (t >> 6)) - 64 (bam_info.cpp:562-570); frames / 32 is exact in fp16
+    half_t f[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t tt = (k >> (8 * c)) & 255u;
+        f[c] = (half_t)((float)((int)(((tt & 63u) + 64u) << (tt >> 6)) - 64) * 0.03125f);
+    }
+    row.z = (uint32_t)__builtin_bit_cast(uint16_t, f[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, f[1]) << 16);
+    row.w = (uint32_t)__builtin_bit_cast(uint16_t, f[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, f[3]) << 16);
+    return row;
+}
+
+// Which map rows do the edge chains read?  A site at view position `off` reads (K1 = 11 | 13):
+//   left chain : E1, E2, E3 at off - 199
+//   right chain: E1 at off + 189 | off + 185, off + 187 ; E2 at off + 185 | off + 177, off + 181 ; E3 at off + 169, off + 177 | off + 169
+template <int K1>
+struct EdgeGeo {
+    static constexpr int L1 = (KMER + 2 - K1) / 2 + 1, L2 = (L1 - 1) / 2 + 1, L3 = (L2 - 1) / 2 + 1;
+    // the last output of a layer over Lin rows takes rows 2(Lout-1)-1 .. +1: (shared, specific, pad) if that ends at Lin,
+    // (shared, shared, specific) if it ends at Lin - 1
+    static constexpr bool PAD2 = 2 * (L2 - 1) + 1 == L1, PAD3 = 2 * (L3 - 1) + 1 == L2, PAD4 = 2 * (C4_LEN - 1) + 1 == L3;
+    // view-position deltas of the shared rows of the right chain (first shared tap; the second, if any, is +step)
+    static constexpr int R1 = -201 + 2 * (2 * (L2 - 1) - 1), R2 = -203 + 4 * (2 * (L3 - 1) - 1), R3 = -207 + 8 * (2 * (C4_LEN - 1) - 1);
+    static constexpr int LEFT = -199;
+    static constexpr int X_LEFT = -201, X_RIGHT = -201 + 2 * (L1 - 1);  // first feature row of conv1's first / last output
+};
+static_assert(EdgeGeo<11>::PAD2 && EdgeGeo<11>::PAD3 && !EdgeGeo<11>::PAD4 && EdgeGeo<11>::R1 == 189 && EdgeGeo<11>::R2 == 185 && EdgeGeo<11>::R3 == 169, "k1 = 11 edge geometry");
+static_assert(!EdgeGeo<13>::PAD2 && !EdgeGeo<13>::PAD3 && EdgeGeo<13>::PAD4 && EdgeGeo<13>::R1 == 185 && EdgeGeo<13>::R2 == 177 && EdgeGeo<13>::R3 == 169, "k1 = 13 edge geometry");
+
+}  // namespace
+
+template <int K1, bool W16>
+__global__ __launch_bounds__(512) void trunk_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views, int ctx,
+                                                     const RInfo* __restrict__ rinfo, const uint8_t* __restrict__ bases,
+                                                     const uint32_t* __restrict__ kin, const uint8_t* __restrict__ sctx,
+                                                     CtxWeights W, TrunkMaps mp) {
+    using G = EdgeGeo<K1>;
+    constexpr int NW = 8;
+    __shared__ __attribute__((aligned(16))) half_t smem[TR_LDS_HALVES];
+    __shared__ uint8_t flags[TR_XROWS];
+    __shared__ int64_t s_grow0;
+    half_t* a_hi = smem;
+    half_t* a_lo = a_hi + TR_AROWS * TR_RS;
+    half_t* b_hi = a_lo + TR_AROWS * TR_RS;
+    half_t* b_lo = b_hi + TR_BROWS * TR_RS;
+    const int n_work = n_tiles * n_views;
+
+    // rows 144..147 of planes A are read by conv2's last position tile (results never used) but never written: keep them finite
+    for (int i = threadIdx.x; i < (TR_AROWS - TR_M1) * TR_RS; i += NW * 64) {
+        a_hi[TR_M1 * TR_RS + i] = (half_t)0.f;
+        a_lo[TR_M1 * TR_RS + i] = (half_t)0.f;
+    }
+
+    // feature rows + map-row flags of work item w -> planes B / flags, by threads [0, nt)
+    auto build = [&](const int w, const int t, const int nt) __attribute__((always_inline)) {
+        const int view = w >= n_tiles;
+        const TrunkTile tl = tiles[view ? w - n_tiles : w];
+        const RInfo ri = rinfo[tl.read_idx];
+        const int L = ri.len;
+        const int64_t bo = ri.base_off;
+        if (t == 0) s_grow0 = (int64_t)view * mp.view_rows + ri.map_off + (tl.u0 + TR_PAD);
+        const int want_base = view ? 2 : 1;  // a site sits on a C of its own strand: forward C, or forward G seen from the reverse strand
+        auto site_at = [&](int y) __attribute__((always_inline)) {  // is view position y a site of this context?
+            if (y < 0 || y >= L) return 0;
+            const int64_t j = bo + (view ? L - 1 - y : y);
+            return (int)(sctx[j] == ctx && bases[j] == want_base);
+        };
+        for (int r = t; r < TR_XROWS; r += nt) {
+            const int x = tl.u0 + r;
+            int b = -1;
+            uint32_t k = 0;
+            if (x >= 0 && x < L) {
+                const int64_t j = bo + (view ? L - 1 - x : x);
+                b = bases[j];
+                k = kin[j];
+            }
+            *reinterpret_cast<uint4*>(b_hi + r * TR_WRS) = feature_row(b, k, view);
+            int f = 0;
+            if (r < TR_OWN) {
+                const int left = site_at(x - G::LEFT);
+                f |= (left | site_at(x - G::R1) | (G::PAD2 ? 0 : site_at(x - G::R1 - 2))) << 0;
+                f |= (left | site_at(x - G::R2) | (G::PAD3 ? 0 : site_at(x - G::R2 - 4))) << 1;
+                f |= (left | site_at(x - G::R3) | (G::PAD4 ? 0 : site_at(x - G::R3 - 8))) << 2;
+            }
+            flags[r] = (uint8_t)f;
+        }
+    };
+
+    // conv1: folded bn0, exact fp16 operand, weights' hi / lo halves stacked along K; dense: every position, taps 1 row apart
+    using C1 = ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, TR_M1, TR_WRS, 1, 8, 4, 1, 0, 0, true, false, false, K1, true, 0, 1, 1>;
+    using C2 = ConvH<NW, 128, 3, 128, TR_M2, TR_RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 1, 1, 2>;
+    using C3 = ConvH<NW, 128, 3, 128, TR_M3, TR_RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 1, 1, 4>;
+    using C4 = ConvH<NW, 128, 3, C4_CH, TR_M4, TR_RS, 1, 6, 3, 1, 0, 0, !W16, true, false, 0, true, 1, 1, 8>;
+    auto wf = [&](int i) { return reinterpret_cast<const half_t*>(W.wfrag_h[i]); };
+
+    if ((int)blockIdx.x < n_work) build(blockIdx.x, threadIdx.x, NW * 64);
+    for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+        __syncthreads();  // feature rows, flags and the map row of this tile are in LDS; the previous conv4 is done with planes A
+        const int64_t grow0 = s_grow0;
+        half_t* g1 = reinterpret_cast<half_t*>(mp.e[0]) + (size_t)grow0 * 256;
+        half_t* g2 = reinterpret_cast<half_t*>(mp.e[1]) + (size_t)grow0 * 256;
+        half_t* g3 = reinterpret_cast<half_t*>(mp.e[2]) + (size_t)grow0 * 256;
+        C1::run(b_hi, b_hi, reinterpret_cast<const half_t*>(W.c1f), EpiTrunk<0>{a_hi, a_lo, W.c1f_bias, flags, g1});
+        __syncthreads();
+        C2::run(a_hi, a_lo, wf(1), EpiTrunk<1>{b_hi, b_lo, W.bias[1], flags, g2});
+        __syncthreads();
+        C3::run(b_hi, b_lo, wf(2), EpiTrunk<2>{a_hi, a_lo, W.bias[2], flags, g3});
+        __syncthreads();
+        // conv4 on 6 waves (96 channels); the other two build the next tile's feature rows in planes B meanwhile
+        C4::run(a_hi, a_lo, wf(3), EpiE4{mp.e4 + (size_t)grow0 * C4_CH, W.bias[3]});
+        const int wn = w + gridDim.x;
+        if (wn < n_work && (int)threadIdx.x >= 384) build(wn, threadIdx.x - 384, 128);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// edge kernel: conv4 rows 0 and 24 of every site.  S sites per pass, two pseudo-rows per site (left edge, right edge):
+//   conv1 (the output that touches the window's zero padding; folded constant taken back for the pad tap)
+//   conv2..conv4: one output each over three taps that are either the previous layer's edge output ("specific"), a row
+//   of the dense map, or the zero padding.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int EG_S = 32, EG_M = 2 * EG_S;
+constexpr int EG_XROWS = 16;  // feature rows per pseudo-row (K1 <= 13 used)
+constexpr int EG_OP = EG_M * 3 * TR_RS;  // halves per operand plane
+constexpr int EG_SP = EG_M * TR_RS;      // halves per "specific" plane
+static_assert(EG_M * EG_XROWS * TR_WRS <= EG_OP, "the feature rows alias the operand plane");
+
+struct EdgeSite {
+    int64_t bo;
+    int64_t vrow;  // map row of view position 0 (incl. the view's plane offset)
+    int L, off, view, valid;
+};
+
+enum { SRC_ZERO = 0, SRC_SPEC = 1, SRC_MAP = 2 };
+struct TapSrc {
+    int kind, delta;
+};
+
+template <int K1>
+__device__ __forceinline__ TapSrc tap_source(int layer, int side, int tap) {
+    using G = EdgeGeo<K1>;
+    if (side == 0) return tap == 0 ? TapSrc{SRC_ZERO, 0} : tap == 1 ? TapSrc{SRC_SPEC, 0} : TapSrc{SRC_MAP, G::LEFT};
+    const bool pad = layer == 2 ? G::PAD2 : layer == 3 ? G::PAD3 : G::PAD4;
+    const int r = layer == 2 ? G::R1 : layer == 3 ? G::R2 : G::R3, step = layer == 2 ? 2 : layer == 3 ? 4 : 8;
+    if (pad) return tap == 0 ? TapSrc{SRC_MAP, r} : tap == 1 ? TapSrc{SRC_SPEC, 0} : TapSrc{SRC_ZERO, 0};
+    return tap == 0 ? TapSrc{SRC_MAP, r} : tap == 1 ? TapSrc{SRC_MAP, r + step} : TapSrc{SRC_SPEC, 0};
+}
+
+// ReLU + split -> the "specific" planes, row m
+struct EpiSpec {
+    half_t* hi;
+    half_t* lo;
+    const float* __restrict__ bias;
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        half4 h, l;
+        split4(acc, h, l);
+        *reinterpret_cast<half4*>(hi + m * TR_RS + col) = h;
+        *reinterpret_cast<half4*>(lo + m * TR_RS + col) = l;
+    }
+};
+
+// conv1's edge outputs: the folded bn0 constant must not count for the tap on the zero padding (c1f_corr, hm_weights.cpp)
+struct EpiSpecC1 {
+    half_t* hi;
+    half_t* lo;
+    const float* __restrict__ bias;
+    const float* __restrict__ corr;  // [2][128]: first output row, last output row
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        const float4 c = *reinterpret_cast<const float4*>(corr + (m >= EG_S ? 128 : 0) + col);
+        half4 h, l;
+        split4(f32x4{acc[0] - c.x, acc[1] - c.y, acc[2] - c.z, acc[3] - c.w}, h, l);
+        *reinterpret_cast<half4*>(hi + m * TR_RS + col) = h;
+        *reinterpret_cast<half4*>(lo + m * TR_RS + col) = l;
+    }
+};
+
+struct EpiEdgeOut {
+    float* __restrict__ out;  // [site][2][96] of this pass
+    const float* __restrict__ bias;
+    int nvalid;
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        const int side = m >= EG_S, site = m - side * EG_S;
+        if (site < nvalid)
+            *reinterpret_cast<float4*>(out + (size_t)site * (2 * C4_CH) + side * C4_CH + col) =
+                make_float4(relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3]));
+    }
+};
+
+}  // namespace
+
+template <int K1, bool W16>
+__global__ __launch_bounds__(512) void edge_kernel(SiteRange sr, const RInfo* __restrict__ rinfo,
+                                                    const uint8_t* __restrict__ bases, const uint32_t* __restrict__ kin,
+                                                    CtxWeights W, TrunkMaps mp, float* __restrict__ edge4,
+                                                    int32_t* __restrict__ e4row) {
+    using G = EdgeGeo<K1>;
+    constexpr int NW = 8;
+    const Site* sites;
+    const int n_sites = resolve_sites(sr, sites);
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * EG_OP + 2 * EG_SP];
+    __shared__ EdgeSite sinfo[EG_S];
+    half_t* op_hi = smem;
+    half_t* op_lo = op_hi + EG_OP;
+    half_t* sp_hi = op_lo + EG_OP;
+    half_t* sp_lo = sp_hi + EG_SP;
+    auto wf = [&](int i) { return reinterpret_cast<const half_t*>(W.wfrag_h[i]); };
+
+    // one 3-tap layer over the staged operand rows [pseudo-row][tap][128]
+    using CE128 = ConvH<NW, 128, 3, 128, 1, TR_RS, 1, 8, 3, EG_M, 3 * TR_RS, 0, !W16, true, false, 0, false, 0, 1, 1>;
+    using CE96 = ConvH<NW, 128, 3, C4_CH, 1, TR_RS, 1, 6, 3, EG_M, 3 * TR_RS, 0, !W16, true, false, 0, false, 0, 1, 1>;
+    using C1E = ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, 1, TR_WRS, 1, 8, 4, EG_M, EG_XROWS * TR_WRS, 0, true, false, false, K1, false, 0, 1, 1>;
+
+    // operand rows of layer `layer` (2..4): specific rows from the previous layer's outputs, shared rows from the map E(layer-1)
+    auto stage = [&](const int layer) __attribute__((always_inline)) {
+        const half_t* __restrict__ map = reinterpret_cast<const half_t*>(mp.e[layer - 2]);
+        constexpr int CHUNKS = EG_M * 3 * 2 * 16;  // 16-byte chunks: pseudo-row x tap x plane x 16
+        for (int i = threadIdx.x; i < CHUNKS; i += NW * 64) {
+            const int q = i & 15, plane = (i >> 4) & 1, rt = i >> 5;
+            const int r = rt / 3, tap = rt - 3 * r;
+            const int side = r >= EG_S, site = r - side * EG_S;
+            const TapSrc src = tap_source<K1>(layer, side, tap);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (src.kind == SRC_SPEC) {
+                v = *reinterpret_cast<const uint4*>((plane ? sp_lo : sp_hi) + r * TR_RS + q * 8);
+            } else if (src.kind == SRC_MAP) {
+                const EdgeSite& es = sinfo[site];
+                v = *reinterpret_cast<const uint4*>(map + (size_t)(es.vrow + es.off + src.delta) * 256 + plane * 128 + q * 8);
+            }
+            *reinterpret_cast<uint4*>((plane ? op_lo : op_hi) + (r * 3 + tap) * TR_RS + q * 8) = v;
+        }
+    };
+
+    for (int s0 = blockIdx.x * EG_S; s0 < n_sites; s0 += gridDim.x * EG_S) {
+        const int nvalid = min(EG_S, n_sites - s0);
+        __syncthreads();  // the previous pass is done with sinfo and the planes
+        if (threadIdx.x < EG_S) {
+            const int i = min((int)threadIdx.x, nvalid - 1);  // pad slots repeat the last site; their results are dropped
+            const Site st = sites[s0 + i];
+            const RInfo ri = rinfo[st.read_idx];
+            EdgeSite es;
+            es.bo = ri.base_off;
+            es.L = ri.len;
+            es.view = bases[ri.base_off + st.qoff] == 2;
+            es.off = es.view ? ri.len - 1 - st.qoff : st.qoff;
+            es.vrow = (int64_t)es.view * mp.view_rows + ri.map_off + TR_PAD;
+            es.valid = (int)threadIdx.x < nvalid;
+            sinfo[threadIdx.x] = es;
+            if (es.valid) e4row[s0 + threadIdx.x] = (int32_t)(es.vrow + es.off - 215);
+        }
+        __syncthreads();
+        // feature rows of conv1's first / last output: K1 rows per pseudo-row, the one on the zero padding all zeros
+        for (int i = threadIdx.x; i < EG_M * EG_XROWS; i += NW * 64) {
+            const int r = i / EG_XROWS, t = i - r * EG_XROWS;
+            const int side = r >= EG_S, site = r - side * EG_S;
+            const EdgeSite& es = sinfo[site];
+            const int x = es.off + (side ? G::X_RIGHT : G::X_LEFT) + t;
+            const bool is_pad = side ? t == K1 - 1 : t == 0;
+            int b = -1;
+            uint32_t k = 0;
+            if (t < K1 && !is_pad && x >= 0 && x < es.L) {
+                const int64_t j = es.bo + (es.view ? es.L - 1 - x : x);
+                b = bases[j];
+                k = kin[j];
+            }
+            *reinterpret_cast<uint4*>(op_hi + i * TR_WRS) = feature_row(b, k, es.view);
+        }
+        __syncthreads();
+        C1E::run(op_hi, op_hi, reinterpret_cast<const half_t*>(W.c1f), EpiSpecC1{sp_hi, sp_lo, W.c1f_bias, W.c1f_corr});
+        __syncthreads();
+        stage(2);
+        __syncthreads();
+        CE128::run(op_hi, op_lo, wf(1), EpiSpec{sp_hi, sp_lo, W.bias[1]});
+        __syncthreads();
+        stage(3);
+        __syncthreads();
+        CE128::run(op_hi, op_lo, wf(2), EpiSpec{sp_hi, sp_lo, W.bias[2]});
+        __syncthreads();
+        stage(4);
+        __syncthreads();
+        CE96::run(op_hi, op_lo, wf(3), EpiEdgeOut{edge4 + (size_t)s0 * (2 * C4_CH), W.bias[3], nvalid});
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+void launch_trunk(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
+                  const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,
+                  const TrunkMaps& maps, int grid, bool w16) {
+    if (n_tiles <= 0) return;
+    const dim3 g(min(n_tiles * n_views, grid)), b(512);
+#define HM_TRUNK(K1, W16) \
+    hipLaunchKernelGGL((trunk_kernel<K1, W16>), g, b, 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, sctx, w, maps)
+    if (k1 == 11) { if (w16) HM_TRUNK(11, true); else HM_TRUNK(11, false); }
+    else { if (w16) HM_TRUNK(13, true); else HM_TRUNK(13, false); }
+#undef HM_TRUNK
+}
+
+void launch_edge(hipStream_t st, int k1, const SiteRange& sr, const RInfo* rinfo, const uint8_t* bases,
+                 const uint32_t* kin, const CtxWeights& w, const TrunkMaps& maps, float* edge4, int32_t* e4row, int grid,
+                 bool w16) {
+    if (sr.cap <= 0) return;
+    const dim3 g(sr.totals ? grid : max(1, min((sr.cap + EG_S - 1) / EG_S, grid))), b(512);
+#define HM_EDGE(K1, W16) hipLaunchKernelGGL((edge_kernel<K1, W16>), g, b, 0, st, sr, rinfo, bases, kin, w, maps, edge4, e4row)
+    if (k1 == 11) { if (w16) HM_EDGE(11, true); else HM_EDGE(11, false); }
+    else { if (w16) HM_EDGE(13, true); else HM_EDGE(13, false); }
+#undef HM_EDGE
+}
+
+size_t trunk_lds_bytes() { return sizeof(half_t) * TR_LDS_HALVES; }
+
+}  // namespace hm
