@@ -82,8 +82,9 @@ constexpr int TR_PAD = 200;   // the maps cover view positions [-200, len + 200)
 
 struct TrunkMaps {
     uint16_t* e[3];     // E1..E3: [2 views][rows][hi 128 | lo 128] fp16 halves (only the rows an edge chain reads are written)
-    float* e4;          // E4: [2 views][rows][96] fp32
+    uint16_t* e4;       // E4: [2 views][rows][hi 96 | lo 96] fp16 halves (what the tail's input planes hold)
     int64_t view_rows;  // rows per view
+    const uint16_t* zeros;  // >= 16 zero bytes (source of padding for the tail's LDS-DMA gather)
 };
 
 // bn0 folded into lookup tables, computed on the host with the ONNX BatchNormalization

@@ -164,7 +164,7 @@ struct hm_engine {
 
     // scratch shared by all batches: only touched by kernels on the compute stream, which runs batches in order
     DevBuf d_act4, d_win, d_dbg, d_stamps;
-    DevBuf d_map[3], d_e4, d_edge4, d_e4row;  // dense trunk: maps of one read group, edge rows of its sites
+    DevBuf d_map[3], d_e4, d_edge4, d_e4row, d_zeros;  // dense trunk: maps of one read group, edge rows of its sites
 
     std::vector<hipEvent_t> pool;
     hm_timing_t acc{};
@@ -503,11 +503,15 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans) {
     e->d_e4.reserve((size_t)max_rows * 2 * C4_CH * sizeof(float));
     e->d_edge4.reserve((size_t)max_bases * 2 * C4_CH * sizeof(float));
     e->d_e4row.reserve((size_t)max_bases * sizeof(int32_t));
+    if (!e->d_zeros.p) {
+        e->d_zeros.reserve(256);
+        HIP_TRY(hipMemsetAsync(e->d_zeros.p, 0, 256, e->stream));
+    }
     const bool w16 = e->precision == 2;
     const int32_t* offs = b->d_offs.as<int32_t>();
     for (const auto& g : b->groups) {
         const TrunkMaps maps{{e->d_map[0].as<uint16_t>(), e->d_map[1].as<uint16_t>(), e->d_map[2].as<uint16_t>()},
-                             e->d_e4.as<float>(), g.rows};
+                             e->d_e4.as<uint16_t>(), g.rows, e->d_zeros.as<uint16_t>()};
         const int n_tiles = g.tile_hi - g.tile_lo;
         for (int c = 0; c < 3; ++c) {
             if (!(e->ctx_mask >> c & 1)) continue;
@@ -524,12 +528,12 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans) {
             {
                 Span sp(e, spans, K_EDGE, c);
                 launch_edge(e->stream, dm.k1, sr, b->d_rinfo.as<RInfo>(), b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), dm.w,
-                            maps, e->d_edge4.as<float>(), e->d_e4row.as<int32_t>(), e->num_cu, w16);
+                            maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(), e->num_cu, w16);
                 sp.end();
             }
             {
                 Span sp(e, spans, K_TAILG, c);
-                launch_tail_gather(e->stream, sr, dm.w, maps, e->d_edge4.as<float>(), e->d_e4row.as<int32_t>(),
+                launch_tail_gather(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
                                    b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu, w16);
                 sp.end();
             }
@@ -690,7 +694,7 @@ void hm_destroy(hm_engine_t* e) {
     e->slots.clear();
     for (auto& m : e->model) m.params.release();
     for (DevBuf* b : {&e->d_act4, &e->d_win, &e->d_dbg, &e->d_stamps, &e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4,
-                      &e->d_edge4, &e->d_e4row})
+                      &e->d_edge4, &e->d_e4row, &e->d_zeros})
         b->release();
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);

@@ -390,15 +390,19 @@ __device__ __forceinline__ void zero_pad_rows_h(half_t* hi, half_t* lo, int rs, 
 
 // GATHER (dense trunk path, hm_trunk.hip): a site's conv4 rows are not read from an act4 hand-off buffer but gathered
 // where they were computed: rows 1..23 are rows e4row[site] + 16 s of the dense E4 map, rows 0 and 24 the site's two
-// window-edge rows from the edge kernel.
+// window-edge rows from the edge kernel.  Both producers write their rows already split ([hi 96 | lo 96] fp16 halves,
+// the same 384 bytes as fp32), so the gather is a pure copy into the input planes: the spare waves of conv6 / conv7 /
+// conv8 issue it as LDS-DMA (global_load_lds_dwordx4: no VGPRs, no VALU split, no ds_write), one 1 KB piece of a plane per
+// wave instruction with a per-lane source address (a zero page for padding rows, row pads and sites past the end).
 template <bool W16, bool GATHER = false>
 __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ act4, SiteRange sr, CtxWeights W,
                                                       float* __restrict__ logits,
                                                       float* __restrict__ prob, uint8_t* __restrict__ ml,
                                                       float* __restrict__ dbg, int dbg_layer,
-                                                      const float* __restrict__ e4 = nullptr,
-                                                      const float* __restrict__ edge4 = nullptr,
-                                                      const int32_t* __restrict__ e4row = nullptr) {
+                                                      const half_t* __restrict__ e4 = nullptr,
+                                                      const half_t* __restrict__ edge4 = nullptr,
+                                                      const int32_t* __restrict__ e4row = nullptr,
+                                                      const half_t* __restrict__ zeros = nullptr) {
     using T = TailGeoH;
     constexpr int S = T::S, NW = 8;
     const Site* sites;
@@ -416,50 +420,118 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
     for (int i = threadIdx.x; i < 2 * 256 + 2; i += NW * 64) fc2w[i] = i < 512 ? W.fc2_w[i] : W.fc2_b[i - 512];
     auto wf = [&](int i) { return reinterpret_cast<const half_t*>(W.wfrag_h[i]); };
 
-    // act4 of a group of S sites = S * 600 float4; thread t owns elements t + 512 k.  The next group's elements are
-    // fetched into registers right after the current ones have been split into LDS, so the HBM/L2 latency of the
-    // 77 KB hand-off hides behind the conv5..fc2 work of the current group.
-    constexpr int Q4 = ACT4_FLOATS / 4, NPRE = (S * Q4 + NW * 64 - 1) / (NW * 64);
-    float4 pre[NPRE];
-    auto fetch = [&](int grp) __attribute__((always_inline)) {
-        const int first = grp * S, nvv = min(S, n_sites - first);
-#pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            const int i = threadIdx.x + k * NW * 64;
-            const int site = i / Q4;
-            pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (GATHER) {
-                if (i < S * Q4 && site < nvv) {
-                    const int rem = (i - site * Q4) * 4, pos = rem / C4_CH, c = rem - pos * C4_CH;
-                    const float* src = pos == 0           ? edge4 + (size_t)(first + site) * (2 * C4_CH) + c
-                                       : pos == C4_LEN - 1 ? edge4 + (size_t)(first + site) * (2 * C4_CH) + C4_CH + c
-                                                           : e4 + ((size_t)e4row[first + site] + 16 * pos) * C4_CH + c;
-                    pre[k] = *reinterpret_cast<const float4*>(src);
-                }
-            } else
-            if (i < S * Q4 && site < nvv) pre[k] = *reinterpret_cast<const float4*>(act4 + (size_t)first * ACT4_FLOATS + (size_t)i * 4);
+    // Input staging.  The conv4 rows of a group of S sites (S * 600 float4: the act4 hand-off, or gathered from the E4 map
+    // and the edge rows) are brought in by the waves that have NO tile in conv6 / conv7 / conv8, one phase ahead of their
+    // use: a wave's vector-memory results return in order, so a prefetch issued by a compute wave stands in front of that
+    // wave's next weight fragment and its full HBM latency is exposed at the head of conv5 (measured: 26 of 77 ms).
+    //   conv6 phase: waves 6,7 REQUEST sites 3..7 of the next group       (conv6 runs on waves 0..5)
+    //   conv7 phase: waves 6,7 split + store them (that part of buffer 0 is dead since conv5); waves 4,5 request sites 0..2
+    //   conv8 phase: waves 4,5 split + store sites 0..2 (conv6's output, which lived there, is dead after conv7);
+    //                wave 7 requests the map rows of the group after next (GATHER)
+    auto wave_id = [&]() __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); };
+    constexpr int Q4 = ACT4_FLOATS / 4;
+    constexpr int SPLIT_SITE = 3;  // S * C6_SS (conv6's output in buffer 0) ends inside site 2's input rows
+    static_assert(S * T::C6_SS <= SPLIT_SITE * T::IN_SS, "conv6's output must not reach the sites staged during conv7");
+    constexpr int NHI = ((S - SPLIT_SITE) * Q4 + 127) / 128, NLO = (SPLIT_SITE * Q4 + 127) / 128;
+    __shared__ int32_t s_row[2][S];  // GATHER: E4 map row (position off - 215) of the sites of the next group
+    auto load_row = [&](int grp, int t) __attribute__((always_inline)) {
+        int32_t r = 0;
+        if (GATHER && t < S && grp * S + t < n_sites) r = e4row[grp * S + t];
+        return r;
+    };
+    // element i (float4 index inside the group) of group `grp`
+    auto elem_src = [&](int grp, int i, int) __attribute__((always_inline)) -> const float* {
+        const int first = grp * S, site = i / Q4;
+        if (first + site >= n_sites) return nullptr;
+        return act4 + (size_t)first * ACT4_FLOATS + (size_t)i * 4;
+    };
+    // ---- GATHER: LDS-DMA staging ----------------------------------------------------------------------------------
+    // A plane of the input (hi or lo) is S * 27 rows of 13 sixteen-byte units (12 data + 1 pad) = 2808 units; piece p
+    // = units [64 p, 64 p + 64) = one wave instruction (the LDS side of an LDS-DMA is wave-uniform base + 16 * lane).
+    constexpr int UNITS = S * (T::L4 + 2) * 13, PIECES = (UNITS + 63) / 64;
+    static_assert(T::RS96 * 2 == 13 * 16 && T::IN_SS == (T::L4 + 2) * T::RS96, "input plane = rows of 13 units");
+    // pieces below LOW_PIECES overlap conv6's output in buffer 0 and may only be written once conv7 has read it
+    constexpr int LOW_PIECES = (S * T::C6_SS * 2 + 1023) / 1024;
+    const int lane = threadIdx.x & 63;
+    auto stage_piece = [&](const int grp, const int p, const int pl, const int rs) __attribute__((always_inline)) {
+        const int u = 64 * p + lane;
+        if (u < UNITS) {
+            const int R = u / 13, ch = u - 13 * R;
+            const int site = R / (T::L4 + 2), prow = R - (T::L4 + 2) * site;
+            const int gs = grp * S + site, pos = prow - 1;
+            const half_t* src = zeros;
+            if (pos >= 0 && pos < C4_LEN && ch < 12 && gs < n_sites) {
+                src = (pos == 0            ? edge4 + (size_t)gs * (4 * C4_CH)
+                       : pos == C4_LEN - 1 ? edge4 + (size_t)gs * (4 * C4_CH) + 2 * C4_CH
+                                           : e4 + ((size_t)s_row[rs][site] + 16 * pos) * (2 * C4_CH)) +
+                      pl * C4_CH + ch * 8;
+            }
+            // M0 = LDS byte address of the piece; the compiler reserves M0, so it is saved and restored around the DMA
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(
+                (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) half_t*)(pl ? l0 : h0) + 1024u * (uint32_t)p);
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
         }
     };
-    if ((int)blockIdx.x * S < n_sites) fetch(blockIdx.x);
+    // pieces [p_lo, p_hi) of plane pl, dealt round-robin to the `nw` waves starting at wave w0
+    auto stage_range = [&](int grp, int pl, int p_lo, int p_hi, int w0, int nw, int rs) __attribute__((always_inline)) {
+        for (int p = p_lo + (wave_id() - w0); p < p_hi; p += nw) stage_piece(grp, p, pl, rs);
+    };
+    auto put_elem = [&](int i, const float4& v) __attribute__((always_inline)) {  // fp32 -> split planes 0, rows 1..25
+        const int site = i / Q4, rem = (i - site * Q4) * 4;
+        const int pos = rem / C4_CH, c = rem - pos * C4_CH;
+        half4 h, l;
+        split4(f32x4{v.x, v.y, v.z, v.w}, h, l);  // conv4 rows are post-ReLU already: the max() is a no-op
+        const int o = site * T::IN_SS + (pos + 1) * T::RS96 + c;
+        *reinterpret_cast<half4*>(h0 + o) = h;
+        *reinterpret_cast<half4*>(l0 + o) = l;
+    };
+    // zero the two padding rows of input sites [s_lo, s_hi) by threads [0, nt)
+    auto zero_in_pads = [&](int s_lo, int s_hi, int t, int nt) __attribute__((always_inline)) {
+        for (int i = t; i < (s_hi - s_lo) * 2 * 96; i += nt) {
+            const int site = s_lo + i / 192, rem = i % 192;
+            const int o = site * T::IN_SS + (rem >= 96 ? (T::L4 + 1) : 0) * T::RS96 + (rem % 96);
+            h0[o] = (half_t)0.f;
+            l0[o] = (half_t)0.f;
+        }
+    };
+    // "defines" v without an instruction.  The staged rows are written by some waves only and read a phase later behind
+    // the same (wave-uniform) condition; the compiler cannot correlate the two branches, so without a definition on the
+    // other paths the registers would count as live around the whole loop -- across conv5 -- and spill.
+    auto fake_def = [](float4& v) __attribute__((always_inline)) { asm volatile("" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)); };
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int32_t pend = 0;
+    int it = 0;
+    float4 phi[NHI], plo[NLO];
+
+    // first group of this workgroup: staged by everybody
+    if constexpr (GATHER) {
+        if ((int)threadIdx.x < S) s_row[0][threadIdx.x] = load_row(blockIdx.x, threadIdx.x);
+        __syncthreads();
+        if (wave == 7) pend = load_row(blockIdx.x + gridDim.x, threadIdx.x - 448);
+    }
+    if ((int)blockIdx.x * S < n_sites) {
+        if constexpr (GATHER) {
+            stage_range(blockIdx.x, 0, 0, PIECES, 0, NW, 0);
+            stage_range(blockIdx.x, 1, 0, PIECES, 0, NW, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA is invisible to the compiler's own wait counting
+        } else {
+            for (int i = threadIdx.x; i < S * Q4; i += NW * 64) {
+                const float* src = elem_src(blockIdx.x, i, 0);
+                put_elem(i, src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+            zero_in_pads(0, S, threadIdx.x, NW * 64);
+        }
+    }
     int slot = 0, g_first = blockIdx.x;  // groups g_first, g_first + gridDim.x, ... wait in ring slots 0 .. slot-1
     for (int g = blockIdx.x; g * S < n_sites; g += gridDim.x) {
-        // act4 [site][25][96] fp32 -> split planes 0, rows 1..25
-#pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            const int i = threadIdx.x + k * NW * 64;
-            if (i < S * Q4) {
-                const int site = i / Q4, rem = (i - site * Q4) * 4;
-                const int pos = rem / C4_CH, c = rem - pos * C4_CH;
-                half4 h, l;
-                split4(f32x4{pre[k].x, pre[k].y, pre[k].z, pre[k].w}, h, l);  // act4 is post-ReLU already: the max() is a no-op
-                const int o = site * T::IN_SS + (pos + 1) * T::RS96 + c;
-                *reinterpret_cast<half4*>(h0 + o) = h;
-                *reinterpret_cast<half4*>(l0 + o) = l;
-            }
+        const bool more = (g + (int)gridDim.x) * S < n_sites;
+        if constexpr (GATHER) {  // map rows of group g + grid (requested one iteration ago) -> LDS
+            ++it;
+            if (wave == 7 && (int)threadIdx.x - 448 < S) s_row[it & 1][threadIdx.x - 448] = pend;
         }
-        if ((g + (int)gridDim.x) * S < n_sites) fetch(g + gridDim.x);
-        zero_pad_rows_h<S, T::L4, 96>(h0, l0, T::RS96, T::IN_SS);
-        __syncthreads();
+        __syncthreads();  // input of group g staged (by the previous iteration's spare waves); s_row visible
 
         ConvH<NW, 96, 3, 96, T::L5, T::RS96, 4, 2, 3, S, T::IN_SS, 0, !W16>::run(
             h0, l0, wf(4), EpiPlanesS<T::L5, T::RS96, T::C5_SS>{h1, l1, W.bias[4]});
@@ -469,20 +541,97 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
 
         // conv6 / conv7 as 1xN grids (a wave owns one 16-channel tile and every position): with 4x2 / 2x4 grids four
         // waves fetched the same weight fragments and the vector-memory pipe, not the MFMA, set the pace
-        ConvH<NW, 96, 3, 96, T::L6, T::RS96, 1, 6, 3, S, T::C5_SS, 0, !W16>::run(
-            h1, l1, wf(5), EpiPlanesS<T::L6, T::RS96, T::C6_SS>{h0, l0, W.bias[5]});
+        // (explicit if / else on the wave id, not a call that returns early: the staged rows must not be live across
+        //  the other waves' conv code or they spill)
+        if (GATHER && wave >= 6) {  // spare in conv6: the hi plane's pieces behind conv6's output, by LDS-DMA
+            if (more) stage_range(g + gridDim.x, 0, LOW_PIECES, PIECES, 6, 2, it & 1);
+        } else if (wave >= 6) {  // spare in conv6: request sites 3..7 of the next group
+            if (more) {
+                int tl = threadIdx.x;
+                asm volatile("" : "+v"(tl));  // keep the element index arithmetic inside the loop (hoisted, it spills)
+#pragma unroll
+                for (int k = 0; k < NHI; ++k) {
+                    const int i = SPLIT_SITE * Q4 + tl - 384 + k * 128;
+                    const float* src = i < S * Q4 ? elem_src(g + gridDim.x, i, it & 1) : nullptr;
+                    phi[k] = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            else {
+#pragma unroll
+                for (int k = 0; k < NHI; ++k) fake_def(phi[k]);
+            }
+        } else {
+            ConvH<NW, 96, 3, 96, T::L6, T::RS96, 1, 6, 3, S, T::C5_SS, 0, !W16>::run(
+                h1, l1, wf(5), EpiPlanesS<T::L6, T::RS96, T::C6_SS>{h0, l0, W.bias[5]});
+#pragma unroll
+            for (int k = 0; k < NHI; ++k) fake_def(phi[k]);
+        }
         zero_pad_rows_h<S, T::L6, 96>(h0, l0, T::RS96, T::C6_SS);
         __syncthreads();
         if (dbg && dbg_layer == 6 && g == 0) dump_planes<T::L6, 96, T::RS96>(h0, l0, dbg);
 
-        ConvH<NW, 96, 3, 64, T::L7, T::RS96, 1, 4, 3, S, T::C6_SS, 0, !W16>::run(
-            h0, l0, wf(6), EpiPlanesS<T::L7, T::RS64, T::C7_SS>{h1, l1, W.bias[6]});
+        if (GATHER && wave >= 4) {  // spare in conv7: the same pieces of the lo plane
+            if (more) stage_range(g + gridDim.x, 1, LOW_PIECES, PIECES, 4, 4, it & 1);
+        } else if (wave >= 6) {  // spare in conv7: the requested rows -> buffer 0 (behind conv6's output)
+            if (more) {
+                int tl = threadIdx.x;
+                asm volatile("" : "+v"(tl));
+#pragma unroll
+                for (int k = 0; k < NHI; ++k) {
+                    const int i = SPLIT_SITE * Q4 + tl - 384 + k * 128;
+                    if (i < S * Q4) put_elem(i, phi[k]);
+                }
+                zero_in_pads(SPLIT_SITE, S, tl - 384, 128);
+            }
+#pragma unroll
+            for (int k = 0; k < NLO; ++k) fake_def(plo[k]);
+        } else if (wave >= 4) {  // request sites 0..2
+            if (more) {
+                int tl = threadIdx.x;
+                asm volatile("" : "+v"(tl));
+#pragma unroll
+                for (int k = 0; k < NLO; ++k) {
+                    const int i = tl - 256 + k * 128;
+                    const float* src = i < SPLIT_SITE * Q4 ? elem_src(g + gridDim.x, i, it & 1) : nullptr;
+                    plo[k] = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NLO; ++k) fake_def(plo[k]);
+            }
+        } else {
+            ConvH<NW, 96, 3, 64, T::L7, T::RS96, 1, 4, 3, S, T::C6_SS, 0, !W16>::run(
+                h0, l0, wf(6), EpiPlanesS<T::L7, T::RS64, T::C7_SS>{h1, l1, W.bias[6]});
+#pragma unroll
+            for (int k = 0; k < NLO; ++k) fake_def(plo[k]);
+        }
         zero_pad_rows_h<S, T::L7, 64>(h1, l1, T::RS64, T::C7_SS);
         __syncthreads();
         if (dbg && dbg_layer == 7 && g == 0) dump_planes<T::L7, 64, T::RS64>(h1, l1, dbg);
 
-        ConvH<NW, 64, 3, 64, T::L8, T::RS64, 1, 4, 3, S, T::C7_SS, 0, !W16>::run(
-            h1, l1, wf(7), EpiRing<T::L8, T::RS64>{r_hi + slot * S * T::RING_SS, r_lo + slot * S * T::RING_SS, W.bias[7]});
+        if (GATHER && wave >= 4) {  // spare in conv8: the pieces that held conv6's output (dead since the last barrier)
+            if (more) {
+                stage_range(g + gridDim.x, 0, 0, LOW_PIECES, 4, 4, it & 1);
+                stage_range(g + gridDim.x, 1, 0, LOW_PIECES, 4, 4, it & 1);
+            }
+            if (wave == 7) pend = load_row(g + 2 * (int)gridDim.x, threadIdx.x - 448);
+            // everything this wave staged for the next group is in LDS before it reaches the barrier in front of conv5
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (wave >= 4) {
+            if (more && wave < 6) {  // spare in conv8: sites 0..2 (conv6's output there is dead since the last barrier)
+                int tl = threadIdx.x;
+                asm volatile("" : "+v"(tl));
+#pragma unroll
+                for (int k = 0; k < NLO; ++k) {
+                    const int i = tl - 256 + k * 128;
+                    if (i < SPLIT_SITE * Q4) put_elem(i, plo[k]);
+                }
+                zero_in_pads(0, SPLIT_SITE, tl - 256, 128);
+            }
+        } else {
+            ConvH<NW, 64, 3, 64, T::L8, T::RS64, 1, 4, 3, S, T::C7_SS, 0, !W16>::run(
+                h1, l1, wf(7), EpiRing<T::L8, T::RS64>{r_hi + slot * S * T::RING_SS, r_lo + slot * S * T::RING_SS, W.bias[7]});
+        }
         if (slot == 0) g_first = g;
         ++slot;
         if (dbg && dbg_layer == 8 && g == 0) {
@@ -492,7 +641,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
                 dbg[i] = (float)r_hi[o] + (float)r_lo[o];
             }
         }
-        if (slot < FCB && (g + (int)gridDim.x) * S < n_sites) continue;  // the loop-top barrier orders this conv8 before the next conv5
+        if (slot < FCB && more) continue;  // the loop-top barrier orders this conv8 before the next conv5
         __syncthreads();
 
         // fc1 as a 2-tap "conv" over conv8's two positions (k order l*64 + c; see hm_weights.cpp), FCB * S sites at once;
@@ -545,22 +694,24 @@ void launch_tail_h(hipStream_t st, const float* act4, const SiteRange& sr, const
     const dim3 g(cnn_grid_h(sr, TAIL_SITES, grid));
     if (w16)
         hipLaunchKernelGGL((tail_kernel_h<true, false>), g, dim3(512), 0, st, act4, sr, w, logits, p, ml, dbg, dbg_layer,
-                           nullptr, nullptr, nullptr);
+                           nullptr, nullptr, nullptr, nullptr);
     else
         hipLaunchKernelGGL((tail_kernel_h<false, false>), g, dim3(512), 0, st, act4, sr, w, logits, p, ml, dbg, dbg_layer,
-                           nullptr, nullptr, nullptr);
+                           nullptr, nullptr, nullptr, nullptr);
 }
 
-void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const float* edge4,
+void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
                         const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, bool w16) {
     if (sr.cap <= 0) return;
     const dim3 g(cnn_grid_h(sr, TAIL_SITES, grid));
     if (w16)
-        hipLaunchKernelGGL((tail_kernel_h<true, true>), g, dim3(512), 0, st, nullptr, sr, w, logits, p, ml, nullptr, 0, maps.e4,
-                           edge4, e4row);
+        hipLaunchKernelGGL((tail_kernel_h<true, true>), g, dim3(512), 0, st, nullptr, sr, w, logits, p, ml, nullptr, 0,
+                           reinterpret_cast<const half_t*>(maps.e4), reinterpret_cast<const half_t*>(edge4), e4row,
+                           reinterpret_cast<const half_t*>(maps.zeros));
     else
-        hipLaunchKernelGGL((tail_kernel_h<false, true>), g, dim3(512), 0, st, nullptr, sr, w, logits, p, ml, nullptr, 0, maps.e4,
-                           edge4, e4row);
+        hipLaunchKernelGGL((tail_kernel_h<false, true>), g, dim3(512), 0, st, nullptr, sr, w, logits, p, ml, nullptr, 0,
+                           reinterpret_cast<const half_t*>(maps.e4), reinterpret_cast<const half_t*>(edge4), e4row,
+                           reinterpret_cast<const half_t*>(maps.zeros));
 }
 
 void launch_front_h(hipStream_t st, int k1, const SiteRange& sr, const ReadDesc* reads, const uint8_t* bases,

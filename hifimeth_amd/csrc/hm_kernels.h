@@ -67,9 +67,9 @@ void launch_trunk(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, i
                   const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,
                   const TrunkMaps& maps, int grid, bool w16);
 void launch_edge(hipStream_t st, int k1, const SiteRange& sr, const RInfo* rinfo, const uint8_t* bases,
-                 const uint32_t* kin, const CtxWeights& w, const TrunkMaps& maps, float* edge4, int32_t* e4row, int grid,
+                 const uint32_t* kin, const CtxWeights& w, const TrunkMaps& maps, uint16_t* edge4, int32_t* e4row, int grid,
                  bool w16);
-void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const float* edge4,
+void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
                         const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, bool w16);
 size_t trunk_lds_bytes();
 

@@ -46,19 +46,31 @@ struct EpiTrunk {
         split4(acc, h, l);
         *reinterpret_cast<half4*>(hi + m * TR_RS + col) = h;
         *reinterpret_cast<half4*>(lo + m * TR_RS + col) = l;
+#if defined(HM_TR_EXP) && HM_TR_EXP >= 1
+        if (false) {
+#else
         if (m < TR_OWN && ((flags[m] >> BIT) & 1)) {
+#endif
             *reinterpret_cast<half4*>(g + (size_t)m * 256 + col) = h;
             *reinterpret_cast<half4*>(g + (size_t)m * 256 + 128 + col) = l;
         }
     }
 };
 
+// conv4 rows leave the trunk already split, [hi 96 | lo 96]: the tail copies them into its input planes as they are
 struct EpiE4 {
-    float* __restrict__ g;
+    half_t* __restrict__ g;
     const float* __restrict__ bias;
     __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
-        *reinterpret_cast<float4*>(g + (size_t)m * C4_CH + col) =
-            make_float4(relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3]));
+        half4 h, l;
+        split4(acc, h, l);
+#if defined(HM_TR_EXP) && HM_TR_EXP >= 2
+        if (h[0] == (half_t)12345.f)  // experiment: no E4 stores (keeps the accumulators live)
+#endif
+        {
+        *reinterpret_cast<half4*>(g + (size_t)m * (2 * C4_CH) + col) = h;
+        *reinterpret_cast<half4*>(g + (size_t)m * (2 * C4_CH) + C4_CH + col) = l;
+        }
     }
 };
 
@@ -182,9 +194,13 @@ __global__ __launch_bounds__(512) void trunk_kernel(const TrunkTile* __restrict_
         C3::run(b_hi, b_lo, wf(2), EpiTrunk<2>{a_hi, a_lo, W.bias[2], flags, g3});
         __syncthreads();
         // conv4 on 6 waves (96 channels); the other two build the next tile's feature rows in planes B meanwhile
-        C4::run(a_hi, a_lo, wf(3), EpiE4{mp.e4 + (size_t)grow0 * C4_CH, W.bias[3]});
+        C4::run(a_hi, a_lo, wf(3), EpiE4{reinterpret_cast<half_t*>(mp.e4) + (size_t)grow0 * (2 * C4_CH), W.bias[3]});
         const int wn = w + gridDim.x;
+#if defined(HM_TR_EXP) && HM_TR_EXP >= 3
+        if (wn < n_work && (int)threadIdx.x == 384) s_grow0 = s_grow0 + TR_OWN;  // experiment: no feature-row build
+#else
         if (wn < n_work && (int)threadIdx.x >= 384) build(wn, threadIdx.x - 384, 128);
+#endif
     }
 }
 
@@ -200,7 +216,7 @@ constexpr int EG_S = 32, EG_M = 2 * EG_S;
 constexpr int EG_XROWS = 16;  // feature rows per pseudo-row (K1 <= 13 used)
 constexpr int EG_OP = EG_M * 3 * TR_RS;  // halves per operand plane
 constexpr int EG_SP = EG_M * TR_RS;      // halves per "specific" plane
-static_assert(EG_M * EG_XROWS * TR_WRS <= EG_OP, "the feature rows alias the operand plane");
+constexpr int EG_XH = EG_M * EG_XROWS * TR_WRS;  // halves of the feature-row buffer
 
 struct EdgeSite {
     int64_t bo;
@@ -252,14 +268,18 @@ struct EpiSpecC1 {
 };
 
 struct EpiEdgeOut {
-    float* __restrict__ out;  // [site][2][96] of this pass
+    half_t* __restrict__ out;  // [site][side][hi 96 | lo 96] of this pass
     const float* __restrict__ bias;
     int nvalid;
     __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
         const int side = m >= EG_S, site = m - side * EG_S;
-        if (site < nvalid)
-            *reinterpret_cast<float4*>(out + (size_t)site * (2 * C4_CH) + side * C4_CH + col) =
-                make_float4(relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3]));
+        if (site < nvalid) {
+            half4 h, l;
+            split4(acc, h, l);
+            half_t* o = out + (size_t)site * (4 * C4_CH) + side * (2 * C4_CH) + col;
+            *reinterpret_cast<half4*>(o) = h;
+            *reinterpret_cast<half4*>(o + C4_CH) = l;
+        }
     }
 };
 
@@ -268,18 +288,20 @@ struct EpiEdgeOut {
 template <int K1, bool W16>
 __global__ __launch_bounds__(512) void edge_kernel(SiteRange sr, const RInfo* __restrict__ rinfo,
                                                     const uint8_t* __restrict__ bases, const uint32_t* __restrict__ kin,
-                                                    CtxWeights W, TrunkMaps mp, float* __restrict__ edge4,
+                                                    CtxWeights W, TrunkMaps mp, uint16_t* __restrict__ edge4,
                                                     int32_t* __restrict__ e4row) {
     using G = EdgeGeo<K1>;
     constexpr int NW = 8;
     const Site* sites;
     const int n_sites = resolve_sites(sr, sites);
-    __shared__ __attribute__((aligned(16))) half_t smem[2 * EG_OP + 2 * EG_SP];
-    __shared__ EdgeSite sinfo[EG_S];
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * EG_OP + 2 * EG_SP + EG_XH];
+    __shared__ EdgeSite sinfo2[2][EG_S];
     half_t* op_hi = smem;
     half_t* op_lo = op_hi + EG_OP;
     half_t* sp_hi = op_lo + EG_OP;
     half_t* sp_lo = sp_hi + EG_SP;
+    half_t* xb = sp_lo + EG_SP;  // feature rows of conv1's edge outputs: [pseudo-row][16 rows][8 halves]
+    EdgeSite* sinfo = sinfo2[0];
     auto wf = [&](int i) { return reinterpret_cast<const half_t*>(W.wfrag_h[i]); };
 
     // one 3-tap layer over the staged operand rows [pseudo-row][tap][128]
@@ -287,31 +309,13 @@ __global__ __launch_bounds__(512) void edge_kernel(SiteRange sr, const RInfo* __
     using CE96 = ConvH<NW, 128, 3, C4_CH, 1, TR_RS, 1, 6, 3, EG_M, 3 * TR_RS, 0, !W16, true, false, 0, false, 0, 1, 1>;
     using C1E = ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, 1, TR_WRS, 1, 8, 4, EG_M, EG_XROWS * TR_WRS, 0, true, false, false, K1, false, 0, 1, 1>;
 
-    // operand rows of layer `layer` (2..4): specific rows from the previous layer's outputs, shared rows from the map E(layer-1)
-    auto stage = [&](const int layer) __attribute__((always_inline)) {
-        const half_t* __restrict__ map = reinterpret_cast<const half_t*>(mp.e[layer - 2]);
-        constexpr int CHUNKS = EG_M * 3 * 2 * 16;  // 16-byte chunks: pseudo-row x tap x plane x 16
-        for (int i = threadIdx.x; i < CHUNKS; i += NW * 64) {
-            const int q = i & 15, plane = (i >> 4) & 1, rt = i >> 5;
-            const int r = rt / 3, tap = rt - 3 * r;
-            const int side = r >= EG_S, site = r - side * EG_S;
-            const TapSrc src = tap_source<K1>(layer, side, tap);
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (src.kind == SRC_SPEC) {
-                v = *reinterpret_cast<const uint4*>((plane ? sp_lo : sp_hi) + r * TR_RS + q * 8);
-            } else if (src.kind == SRC_MAP) {
-                const EdgeSite& es = sinfo[site];
-                v = *reinterpret_cast<const uint4*>(map + (size_t)(es.vrow + es.off + src.delta) * 256 + plane * 128 + q * 8);
-            }
-            *reinterpret_cast<uint4*>((plane ? op_lo : op_hi) + (r * 3 + tap) * TR_RS + q * 8) = v;
-        }
-    };
-
-    for (int s0 = blockIdx.x * EG_S; s0 < n_sites; s0 += gridDim.x * EG_S) {
+    // Site descriptors + feature rows of the pass that starts at site s0, by threads [0, nt) (t < 0: not taking part).
+    // A dependent chain of loads (site -> read -> base) followed by 1024 row builds: done for the NEXT pass by the two
+    // waves that have no tile in the last layer (96 channels = 6 waves), so that a pass starts with everything in LDS.
+    auto prepare = [&](const int s0, EdgeSite* si, const int t, const int nt) __attribute__((always_inline)) {
         const int nvalid = min(EG_S, n_sites - s0);
-        __syncthreads();  // the previous pass is done with sinfo and the planes
-        if (threadIdx.x < EG_S) {
-            const int i = min((int)threadIdx.x, nvalid - 1);  // pad slots repeat the last site; their results are dropped
+        if (t >= 0 && t < EG_S) {
+            const int i = min(t, nvalid - 1);  // pad slots repeat the last site; their results are dropped
             const Site st = sites[s0 + i];
             const RInfo ri = rinfo[st.read_idx];
             EdgeSite es;
@@ -320,41 +324,131 @@ __global__ __launch_bounds__(512) void edge_kernel(SiteRange sr, const RInfo* __
             es.view = bases[ri.base_off + st.qoff] == 2;
             es.off = es.view ? ri.len - 1 - st.qoff : st.qoff;
             es.vrow = (int64_t)es.view * mp.view_rows + ri.map_off + TR_PAD;
-            es.valid = (int)threadIdx.x < nvalid;
-            sinfo[threadIdx.x] = es;
-            if (es.valid) e4row[s0 + threadIdx.x] = (int32_t)(es.vrow + es.off - 215);
+            es.valid = t < nvalid;
+            si[t] = es;
+            if (es.valid) e4row[s0 + t] = (int32_t)(es.vrow + es.off - 215);
         }
-        __syncthreads();
-        // feature rows of conv1's first / last output: K1 rows per pseudo-row, the one on the zero padding all zeros
-        for (int i = threadIdx.x; i < EG_M * EG_XROWS; i += NW * 64) {
-            const int r = i / EG_XROWS, t = i - r * EG_XROWS;
+    };
+    // feature rows of conv1's first / last output: K1 rows per pseudo-row, the one on the zero padding all zeros
+    auto build_rows = [&](const EdgeSite* si, const int t, const int nt) __attribute__((always_inline)) {
+        for (int i = t; i < EG_M * EG_XROWS; i += nt) {
+            const int r = i / EG_XROWS, tt = i - r * EG_XROWS;
             const int side = r >= EG_S, site = r - side * EG_S;
-            const EdgeSite& es = sinfo[site];
-            const int x = es.off + (side ? G::X_RIGHT : G::X_LEFT) + t;
-            const bool is_pad = side ? t == K1 - 1 : t == 0;
+            const EdgeSite& es = si[site];
+            const int x = es.off + (side ? G::X_RIGHT : G::X_LEFT) + tt;
+            const bool is_pad = side ? tt == K1 - 1 : tt == 0;
             int b = -1;
             uint32_t k = 0;
-            if (t < K1 && !is_pad && x >= 0 && x < es.L) {
+            if (tt < K1 && !is_pad && x >= 0 && x < es.L) {
                 const int64_t j = es.bo + (es.view ? es.L - 1 - x : x);
                 b = bases[j];
                 k = kin[j];
             }
-            *reinterpret_cast<uint4*>(op_hi + i * TR_WRS) = feature_row(b, k, es.view);
+            *reinterpret_cast<uint4*>(xb + i * TR_WRS) = feature_row(b, k, es.view);
         }
+    };
+
+    // Shared (map) rows of layer `LAYER` (2..4) of all pseudo-rows: left chains read one row, right chains one or two.
+    // They depend on the sites only, not on anything computed here, so a pass REQUESTS all of them (three layers) right
+    // after its site descriptors are known and parks them in registers; the HBM latency then hides behind the feature
+    // rows and conv1 instead of standing in front of every layer.
+    auto n_map_chunks = [](int layer) constexpr {
+        const bool pad = layer == 2 ? G::PAD2 : layer == 3 ? G::PAD3 : G::PAD4;
+        return EG_S * (pad ? 2 : 3) * 32 / (NW * 64);  // rows x 32 sixteen-byte chunks / threads
+    };
+    constexpr int NC2 = n_map_chunks(2), NC3 = n_map_chunks(3), NC4 = n_map_chunks(4);
+    uint4 m2[NC2], m3[NC3], m4[NC4];
+    auto map_chunk = [&](const int layer, const int j, int& r, int& tap, int& plane, int& q, int& delta) __attribute__((always_inline)) {
+        const int c = threadIdx.x + NW * 64 * j, mr = c >> 5;
+        plane = (c >> 4) & 1;
+        q = c & 15;
+        const int grp = mr / EG_S, site = mr - grp * EG_S;  // 0: left chain, 1 / 2: first / second shared tap of the right chain
+        const int rr = layer == 2 ? G::R1 : layer == 3 ? G::R2 : G::R3, step = layer == 2 ? 2 : layer == 3 ? 4 : 8;
+        r = grp == 0 ? site : EG_S + site;
+        tap = grp == 0 ? 2 : grp - 1;
+        delta = grp == 0 ? G::LEFT : rr + (grp - 1) * step;
+        return site;
+    };
+    auto request = [&](auto ltag) __attribute__((always_inline)) {
+        constexpr int LAYER = decltype(ltag)::value, N = n_map_chunks(LAYER);
+        const half_t* __restrict__ map = reinterpret_cast<const half_t*>(mp.e[LAYER - 2]);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            int r, tap, plane, q, delta;
+            const int site = map_chunk(LAYER, j, r, tap, plane, q, delta);
+            const EdgeSite& es = sinfo[site];
+            const uint4 v = *reinterpret_cast<const uint4*>(map + (size_t)(es.vrow + es.off + delta) * 256 + plane * 128 + q * 8);
+            if constexpr (LAYER == 2) m2[j] = v;
+            else if constexpr (LAYER == 3) m3[j] = v;
+            else m4[j] = v;
+        }
+    };
+    // operand rows of layer LAYER: the parked map rows, the previous layer's edge outputs ("specific"), zero padding
+    auto stage = [&](auto ltag) __attribute__((always_inline)) {
+        constexpr int LAYER = decltype(ltag)::value, N = n_map_chunks(LAYER);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            int r, tap, plane, q, delta;
+            map_chunk(LAYER, j, r, tap, plane, q, delta);
+            uint4 v;
+            if constexpr (LAYER == 2) v = m2[j];
+            else if constexpr (LAYER == 3) v = m3[j];
+            else v = m4[j];
+            *reinterpret_cast<uint4*>((plane ? op_lo : op_hi) + (r * 3 + tap) * TR_RS + q * 8) = v;
+        }
+        constexpr int CHUNKS = EG_M * 3 * 2 * 16;  // 16-byte chunks: pseudo-row x tap x plane x 16
+        for (int i = threadIdx.x; i < CHUNKS; i += NW * 64) {
+            const int q = i & 15, plane = (i >> 4) & 1, rt = i >> 5;
+            const int r = rt / 3, tap = rt - 3 * r;
+            const TapSrc src = tap_source<K1>(LAYER, r >= EG_S, tap);
+            if (src.kind == SRC_MAP) continue;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (src.kind == SRC_SPEC) v = *reinterpret_cast<const uint4*>((plane ? sp_lo : sp_hi) + r * TR_RS + q * 8);
+            *reinterpret_cast<uint4*>((plane ? op_lo : op_hi) + (r * 3 + tap) * TR_RS + q * 8) = v;
+        }
+    };
+    using L2t = std::integral_constant<int, 2>;
+    using L3t = std::integral_constant<int, 3>;
+    using L4t = std::integral_constant<int, 4>;
+
+    if ((int)blockIdx.x * EG_S < n_sites) {  // first pass of this workgroup: prepared by everybody
+        prepare(blockIdx.x * EG_S, sinfo2[0], threadIdx.x, NW * 64);
         __syncthreads();
-        C1E::run(op_hi, op_hi, reinterpret_cast<const half_t*>(W.c1f), EpiSpecC1{sp_hi, sp_lo, W.c1f_bias, W.c1f_corr});
+        build_rows(sinfo2[0], threadIdx.x, NW * 64);
+    }
+    int cur = 0;
+    for (int s0 = blockIdx.x * EG_S; s0 < n_sites; s0 += gridDim.x * EG_S) {
+        const int nvalid = min(EG_S, n_sites - s0);
+        sinfo = sinfo2[cur];
+        __syncthreads();  // descriptors + feature rows of this pass are in LDS; the previous pass is done with the planes
+        request(L2t{});
+        C1E::run(xb, xb, reinterpret_cast<const half_t*>(W.c1f), EpiSpecC1{sp_hi, sp_lo, W.c1f_bias, W.c1f_corr});
+        // requested behind conv1's own (weight) loads: a wave's loads return in order, so in front of them these rows would
+        // have to arrive before conv1 could start
+        request(L3t{});
+        request(L4t{});
         __syncthreads();
-        stage(2);
+        stage(L2t{});
         __syncthreads();
         CE128::run(op_hi, op_lo, wf(1), EpiSpec{sp_hi, sp_lo, W.bias[1]});
         __syncthreads();
-        stage(3);
+        stage(L3t{});
         __syncthreads();
         CE128::run(op_hi, op_lo, wf(2), EpiSpec{sp_hi, sp_lo, W.bias[2]});
         __syncthreads();
-        stage(4);
+        stage(L4t{});
         __syncthreads();
-        CE96::run(op_hi, op_lo, wf(3), EpiEdgeOut{edge4 + (size_t)s0 * (2 * C4_CH), W.bias[3], nvalid});
+        const int sn = s0 + gridDim.x * EG_S;
+        if ((int)threadIdx.x >= 384) {  // waves 6, 7 have no tile in the 96-channel layer: they prepare the next pass
+            if (sn < n_sites && (int)threadIdx.x < 448) {  // one wave: its descriptors are visible to itself without a barrier
+                prepare(sn, sinfo2[cur ^ 1], threadIdx.x - 384, 64);
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the descriptors are in LDS before this wave reads them back
+                build_rows(sinfo2[cur ^ 1], threadIdx.x - 384, 64);
+            }
+        } else {
+            CE96::run(op_hi, op_lo, wf(3), EpiEdgeOut{reinterpret_cast<half_t*>(edge4) + (size_t)s0 * (4 * C4_CH), W.bias[3], nvalid});
+        }
+        cur ^= 1;
     }
 }
 
@@ -372,7 +466,7 @@ void launch_trunk(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, i
 }
 
 void launch_edge(hipStream_t st, int k1, const SiteRange& sr, const RInfo* rinfo, const uint8_t* bases,
-                 const uint32_t* kin, const CtxWeights& w, const TrunkMaps& maps, float* edge4, int32_t* e4row, int grid,
+                 const uint32_t* kin, const CtxWeights& w, const TrunkMaps& maps, uint16_t* edge4, int32_t* e4row, int grid,
                  bool w16) {
     if (sr.cap <= 0) return;
     const dim3 g(sr.totals ? grid : max(1, min((sr.cap + EG_S - 1) / EG_S, grid))), b(512);
