@@ -56,7 +56,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(reads, gpu_calls=None, budget_s=15.0):
+def cpu_baseline(reads, gpu_calls=None, budget_s=15.0, tol=1e-4):
     """The CPU oracle (port of the reference path) timed on this node's host cores, bounded sample.
     The oracle's results for that sample double as an in-run parity check of the GPU calls."""
     from oracle import hm_oracle as O
@@ -98,7 +98,8 @@ def cpu_baseline(reads, gpu_calls=None, budget_s=15.0):
     if gpu_calls is not None:
         alld = np.concatenate(deltas) if deltas else np.zeros(1)
         parity = {"sites_checked": ncheck, "max_abs_dp_vs_oracle": worst, "mean_abs_dp": float(alld.mean()),
-                  "p999_abs_dp": float(np.quantile(alld, 0.999)), "ml_bytes_off_by_1lsb": nml, "tolerance": 1e-4}
+                  "p999_abs_dp": float(np.quantile(alld, 0.999)), "ml_bytes_off_by_1lsb": nml, "tolerance": tol,
+                  "frac_above_1e-4": float((alld > 1e-4).mean()), "frac_above_1e-3": float((alld > 1e-3).mean())}
     return out, parity
 
 
@@ -134,8 +135,9 @@ def main():
     ap.add_argument("--pool", type=int, default=8, help="distinct slabs synthesised up front; steps cycle through them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (fp32 mode, resident slab, windows)")
-    ap.add_argument("--precision", type=int, default=1, choices=[0, 1, 2],
-                    help="CNN arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA, 2 = fp16 weights")
+    ap.add_argument("--precision", type=int, default=1, choices=[0, 1, 2, 3],
+                    help="CNN arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA, 2 = fp16 weights in "
+                         "conv6..conv8 (holds the 1e-3 bar of configs[4]), 3 = fp16 weights in conv2..conv8 (misses it)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (e.g. front_waves=8)")
     args = ap.parse_args()
 
@@ -302,7 +304,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {0: "f32", 1: "f16x3+f32acc", 2: "f16w/f16x2+f32acc"}[args.precision],
+            "dtype": {0: "f32", 1: "f16x3+f32acc", 2: "f16x3+f32acc, f16 weights conv6-8", 3: "f16w/f16x2+f32acc"}[args.precision],
             "cnn_path": "dense trunk (conv1..conv4 once per read position) + per-site edge rows + tail" if trunk_ms > 0
                         else "per site (front + tail kernels)",
             "data": "synthetic",
@@ -323,7 +325,7 @@ def main():
         }
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline and gpu_calls is not None:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(slabs[0][:96], gpu_calls)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(slabs[0][:96], gpu_calls, tol=1e-4 if args.precision <= 1 else 1e-3)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             # external sanity bound, DERIVED not measured: the reference README's "~2 hours on 48
             # CPU threads" for 30x Arabidopsis, ~1.1e9 sites => ~1.5e5 sites/s; the north-star asks for >= 30x of it

@@ -4,7 +4,9 @@
 // Reads keep their input order; reads shorter than -l or without complete kinetics are passed through with the
 // kinetics / old MM / ML tags stripped, exactly as the reference does.
 // Two extra sub-commands need no GPU and exist for the CPU test-suite:
-//     hifimeth-hip bamcopy IN.bam OUT.bam             (BGZF/BAM round trip)
+//     hifimeth-hip bamcopy [-R r/w] IN.bam OUT.bam    (BGZF/BAM round trip, optionally of one rank's shard)
+//     hifimeth-hip merge OUT.bam N                    (joins OUT.bam.shard0..N-1 written by N ranks of call / bamcopy -R)
+//     hifimeth-hip stagebench [-t N] [-R r/w] IN.bam  (host side of call without a GPU: inflate + parse + stage; JSON rate)
 //     hifimeth-hip tagtest IN.bam CALLS.bin OUT.bam   (apply hm_call_t records, read_id = record index)
 //     hifimeth-hip pileup [OPTIONS] REF.fa MOD.bam PREFIX   (hifimeth_pileup.cpp)
 //     hifimeth-hip corr [-c N] A.cov.bed B.cov.bed          (Pearson r of two pileup outputs, hifimeth_pileup.cpp)
@@ -34,6 +36,10 @@ namespace {
 const char* kName = "hifimeth-hip";
 const char* kVersion = "0.1.0";
 
+struct Shard {  // -R r/w: this process handles the r-th of w parts of the input (see open_shard)
+    int rank = 0, world = 1;
+};
+
 struct Options {
     std::string model_dir;
     int min_read_size = 1000;  // mod_options.cpp:10-17
@@ -46,6 +52,8 @@ struct Options {
     int precision = 1;
     std::vector<int> devices{0};
     std::string in, out;
+    bool help = false;
+    Shard shard;
 };
 
 void usage() {
@@ -57,12 +65,14 @@ void usage() {
             "  -b <int>     reads per batch (default 10000)\n"
             "  -k           keep the kinetics tags fi/ri/fp/rp in the output\n"
             "  -c <list>    contexts to call: cpg,chg,chh (default all)\n"
-            "  -t <int>     host threads for BGZF inflate/deflate (default: all, max 16)\n"
+            "  -t <int>     host threads for BGZF inflate/deflate and tag building (default: all)\n"
             "  -d <list>    GPU ordinals, e.g. 0,1,2,3 (default 0)\n"
-            "  -p <0|1|2>   arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA,\n"
-            "               2 = fp16 weights for conv2..conv8 (|dp| <= 1e-3 mode)\n"
+            "  -p <0..3>    arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA,\n"
+            "               2 = fp16 weights in conv6..conv8 (|dp| <= 1e-3 mode), 3 = fp16 weights in conv2..conv8\n"
+            "  -R <r/w>     this process is rank r of w: call only the r-th part of BAM (split by BGZF offset) and write\n"
+            "               MOD-BAM.shard<r>; `%s merge MOD-BAM w` joins the shards in input order\n"
             "  -z <0-9>     output compression level (default 6)\n",
-            kName);
+            kName, kName);
 }
 
 bool parse_ctx(const char* arg, int& mask) {
@@ -125,7 +135,20 @@ bool parse(int argc, char** argv, Options& o) {
                 } else tok += s[k];
             }
             if (o.devices.empty()) return false;
-        } else if (a == "-h" || a == "-v") return false;
+        } else if (a == "-R") {
+            if (i + 1 >= argc || sscanf(argv[++i], "%d/%d", &o.shard.rank, &o.shard.world) != 2 || o.shard.world < 1 ||
+                o.shard.rank < 0 || o.shard.rank >= o.shard.world) {
+                fprintf(stderr, "Illegal argument to option '-R' (rank/world expected)\n");
+                return false;
+            }
+        } else if (a == "-h") {
+            o.help = true;
+            return false;
+        } else if (a == "-v") {
+            fprintf(stderr, "%s\n", kVersion);
+            o.help = true;
+            return false;
+        }
         else if (a[0] == '-' && a.size() > 1) {
             fprintf(stderr, "Unrecognised option '%s'\n", a.c_str());
             return false;
@@ -135,8 +158,8 @@ bool parse(int argc, char** argv, Options& o) {
     o.in = argv[i];
     o.out = argv[i + 1];
     if (o.model_dir.empty()) o.model_dir = exe_dir() + "/../weights";
-    if (o.threads <= 0) o.threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (o.read_batch < 1 || o.min_read_size < 0 || o.level < 0 || o.level > 9 || o.precision < 0 || o.precision > 2) return false;
+    if (o.threads <= 0) o.threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (o.read_batch < 1 || o.min_read_size < 0 || o.level < 0 || o.level > 9 || o.precision < 0 || o.precision > 3) return false;
     return true;
 }
 
@@ -147,82 +170,95 @@ void add_pg(BamHeader& h, int argc, char** argv) {  // mod_main.cpp:101-117
     h.text += line + "\n";
 }
 
-struct Slot {
-    hm_engine_t* eng = nullptr;
+// ---- read sharding over processes ---------------------------------------------------------------------------------------
+// `-R r/w`: this process is rank r of w.  The input is split by COMPRESSED bytes at BGZF block boundaries, so a rank
+// inflates only its own part of the file (the reference's single reader, src/corelib/sam_batch.hpp:12-54, is what limits
+// it to one node's worth of decode).  A record belongs to the rank whose byte range holds the block its first byte is in;
+// ranks > 0 find their first record with find_record_start.  Every rank writes <out>.shard<r>; `merge` joins them in rank
+// order, which is input order (mod_main.cpp:352-362 writes in input order).
+bool parse_shard(const char* arg, Shard& sh) {
+    return sscanf(arg, "%d/%d", &sh.rank, &sh.world) == 2 && sh.world >= 1 && sh.rank >= 0 && sh.rank < sh.world;
+}
+
+std::string shard_path(const std::string& out, const Shard& sh) {
+    return sh.world == 1 ? out : out + ".shard" + std::to_string(sh.rank);
+}
+
+// reads the header (every rank needs the reference count), then positions `in` at the shard's first record;
+// end_off = compressed offset at which the next rank's records start
+bool open_shard(BgzfReader& in, const std::string& path, const Shard& sh, BamHeader& hdr, int64_t& end_off, std::string& err) {
+    if (!read_header(in, hdr, err)) return false;
+    end_off = INT64_MAX;
+    if (sh.world == 1) return true;
+    std::vector<int64_t> offs;
+    int64_t fsize = 0;
+    if (!scan_bgzf_blocks(path, offs, fsize, err)) return false;
+    const int64_t first_rec_block = in.block_offset();
+    auto bound = [&](int k) -> int64_t {
+        if (k >= sh.world) return fsize;
+        const int64_t target = fsize / sh.world * k;
+        auto it = std::lower_bound(offs.begin(), offs.end(), target);
+        const int64_t b = it == offs.end() ? fsize : *it;
+        return std::max(b, first_rec_block);  // ranges that would start inside the header collapse onto the first record
+    };
+    const int64_t start = bound(sh.rank);
+    end_off = bound(sh.rank + 1);
+    if (start >= end_off) {  // empty shard
+        end_off = -1;
+        return true;
+    }
+    if (start == first_rec_block) return true;  // begins right behind the header: the reader is already there
+    if (!in.seek_block(start)) { err = in.error(); return false; }
+    if (!find_record_start(in, (int)hdr.refs.size(), err)) {
+        if (!err.empty()) return false;
+        end_off = -1;  // no record starts in this range
+    }
+    return true;
+}
+
+struct Job {
+    hm_batch_t* batch = nullptr;
     std::vector<BamRecord> recs;
-    bool active = false;
+    size_t dev = 0;
 };
 
 int cmd_call(int argc, char** argv) {
     Options o;
     if (!parse(argc, argv, o)) {
         usage();
-        return EXIT_FAILURE;
+        return o.help ? 0 : EXIT_FAILURE;  // -h / -v exit 0 like the reference (mod_options.cpp:62-71)
     }
     const auto t0 = std::chrono::steady_clock::now();
     BgzfReader in(o.in, o.threads);
     if (!in.ok()) { fprintf(stderr, "[%s] %s\n", kName, in.error().c_str()); return EXIT_FAILURE; }
     BamHeader hdr;
     std::string err;
-    if (!read_header(in, hdr, err)) { fprintf(stderr, "[%s] %s: %s\n", kName, o.in.c_str(), err.c_str()); return EXIT_FAILURE; }
-    BgzfWriter out(o.out, o.threads, o.level);
+    int64_t end_off = 0;
+    if (!open_shard(in, o.in, o.shard, hdr, end_off, err)) { fprintf(stderr, "[%s] %s: %s\n", kName, o.in.c_str(), err.c_str()); return EXIT_FAILURE; }
+    BgzfWriter out(shard_path(o.out, o.shard), o.threads, o.level);
     if (!out.ok()) { fprintf(stderr, "[%s] %s\n", kName, out.error().c_str()); return EXIT_FAILURE; }
-    add_pg(hdr, argc, argv);
-    write_header(out, hdr);
+    if (o.shard.rank == 0) {
+        add_pg(hdr, argc, argv);
+        write_header(out, hdr);
+    }
 
-    // three engines per device: one batch being staged, one on the GPU, one being tagged / written
-    std::vector<Slot> slots(o.devices.size() * 3);
-    for (size_t s = 0; s < slots.size(); ++s) {
-        const int dev = o.devices[s % o.devices.size()];
-        if (hm_create(&slots[s].eng, o.model_dir.c_str(), o.ctx_mask, dev) < 0) {
-            fprintf(stderr, "[%s] device %d: %s\n", kName, dev, hm_last_error(nullptr));
+    // one engine per device, three batch slots each: one being staged, one on the GPU, one being tagged / written
+    std::vector<hm_engine_t*> eng(o.devices.size(), nullptr);
+    for (size_t d = 0; d < eng.size(); ++d) {
+        if (hm_create(&eng[d], o.model_dir.c_str(), o.ctx_mask, o.devices[d]) < 0) {
+            fprintf(stderr, "[%s] device %d: %s\n", kName, o.devices[d], hm_last_error(nullptr));
             return EXIT_FAILURE;
         }
-        hm_set_option(slots[s].eng, "min_read_size", o.min_read_size);
-        hm_set_option(slots[s].eng, "precision", o.precision);
+        hm_set_option(eng[d], "min_read_size", o.min_read_size);
+        hm_set_option(eng[d], "precision", o.precision);
+        hm_set_option(eng[d], "slots", 3);
     }
     size_t all_reads = 0, all_bases = 0, all_ctx[3] = {0, 0, 0};
-    std::vector<hm_call_t> calls;
     std::atomic<bool> failed{false};
 
-    auto finish = [&](Slot& sl) {
-        hm_engine_t* e = sl.eng;
-        if (hm_sync(e) < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(e)); failed = true; return; }
-        const int64_t n = hm_num_sites(e, HM_CTX_ALL);
-        for (int c = 0; c < 3; ++c) all_ctx[c] += (size_t)std::max<int64_t>(0, hm_num_sites(e, c));
-        calls.resize((size_t)std::max<int64_t>(n, 0));
-        const int64_t got = hm_drain(e, calls.data(), (int64_t)calls.size());
-        if (got < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(e)); failed = true; return; }
-        // calls are grouped by read in submission order: find every read's range, then build the tags of all reads
-        // in parallel (the MM deltas walk every base of the read), then write in order
-        std::vector<size_t> first(sl.recs.size() + 1, 0);
-        size_t ci = 0;
-        for (size_t i = 0; i < sl.recs.size(); ++i) {
-            first[i] = ci;
-            while (ci < (size_t)got && calls[ci].read_id == (int32_t)i) ++ci;
-        }
-        first[sl.recs.size()] = ci;
-        std::vector<std::string> errs(sl.recs.size());
-        parallel_run((int)sl.recs.size(), o.threads, [&](int i) {
-            apply_calls(sl.recs[(size_t)i], calls.data() + first[(size_t)i], first[(size_t)i + 1] - first[(size_t)i],
-                        o.keep_kinetics, errs[(size_t)i]);
-        });
-        for (size_t i = 0; i < sl.recs.size(); ++i) {
-            if (!errs[i].empty()) {
-                fprintf(stderr, "[%s] read %zu: %s\n", kName, all_reads + i, errs[i].c_str());
-                failed = true;
-                return;
-            }
-            all_bases += (size_t)sl.recs[i].l_qseq();
-            write_record(out, sl.recs[i]);
-        }
-        all_reads += sl.recs.size();
-        fprintf(stderr, "[%s] %zu reads done\n", kName, all_reads);
-        sl.recs.clear();
-    };
-
-    // A producer thread inflates and parses batch k+1 while this thread stages batch k, collects an older batch from
-    // its engine, builds its tags and deflates it (the reader is touched by the producer only, the writer by this thread).
+    // A producer thread inflates and parses batch k+1 while this thread stages batch k into a free slot of the least
+    // loaded device (a pull queue: a device takes work whenever one of its slots frees up); a consumer thread collects
+    // finished batches in submission order, builds the tags on the host threads and deflates.
     struct Batch {
         std::vector<BamRecord> recs;
         bool eof = false;
@@ -233,35 +269,88 @@ int cmd_call(int argc, char** argv) {
         bt.recs.clear();
         bt.err.clear();
         while ((int)bt.recs.size() < o.read_batch) {
+            if (end_off < 0 || in.block_offset() >= end_off) { bt.eof = true; break; }  // the next record is another rank's
             BamRecord r;
             if (!read_record(in, r, bt.err)) { bt.eof = true; break; }
             bt.recs.push_back(std::move(r));
         }
     };
-    // consumer thread: collects finished batches in submission order (hm_sync + hm_drain), builds the tags, deflates
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<size_t> ready;
+    std::deque<Job> ready;
+    std::vector<int> inflight(eng.size(), 0);
     bool no_more = false;
+
+    auto finish = [&](Job& jb) {
+        const hm_call_t* calls = nullptr;
+        const int64_t got = hm_batch_wait(jb.batch, &calls);
+        if (got < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(eng[jb.dev])); failed = true; return; }
+        for (int c = 0; c < 3; ++c) all_ctx[c] += (size_t)std::max<int64_t>(0, hm_batch_num_sites(jb.batch, c));
+        // calls are grouped by read in submission order: find every read's range, then build the tags of all reads
+        // in parallel (the MM deltas walk every base of the read), then write in order
+        std::vector<size_t> first(jb.recs.size() + 1, 0);
+        size_t ci = 0;
+        for (size_t i = 0; i < jb.recs.size(); ++i) {
+            first[i] = ci;
+            while (ci < (size_t)got && calls[ci].read_id == (int32_t)i) ++ci;
+        }
+        first[jb.recs.size()] = ci;
+        std::vector<std::string> errs(jb.recs.size());
+        parallel_run((int)jb.recs.size(), o.threads, [&](int i) {
+            apply_calls(jb.recs[(size_t)i], calls + first[(size_t)i], first[(size_t)i + 1] - first[(size_t)i], o.keep_kinetics,
+                        errs[(size_t)i]);
+        });
+        hm_batch_release(jb.batch);  // the pinned result view is no longer needed: the slot can take the next batch
+        jb.batch = nullptr;
+        for (size_t i = 0; i < jb.recs.size(); ++i) {
+            if (!errs[i].empty()) {
+                fprintf(stderr, "[%s] read %zu: %s\n", kName, all_reads + i, errs[i].c_str());
+                failed = true;
+                return;
+            }
+            all_bases += (size_t)jb.recs[i].l_qseq();
+            write_record(out, jb.recs[i]);
+        }
+        all_reads += jb.recs.size();
+        fprintf(stderr, "[%s] %zu reads done\n", kName, all_reads);
+    };
     std::thread writer([&]() {
         for (;;) {
-            size_t idx;
+            Job jb;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return !ready.empty() || no_more; });
                 if (ready.empty()) return;
-                idx = ready.front();
+                jb = std::move(ready.front());
                 ready.pop_front();
             }
-            if (!failed) finish(slots[idx]);
+            if (!failed) finish(jb);
+            if (jb.batch) hm_batch_release(jb.batch);
             {
                 std::lock_guard<std::mutex> lk(mu);
-                slots[idx].active = false;
+                --inflight[jb.dev];
             }
             cv.notify_all();
         }
     });
-    size_t b = 0;
+    auto launch = [&](Job&& jb) {
+        if (hm_batch_enqueue(jb.batch) < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(eng[jb.dev])); failed = true; return; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ready.push_back(std::move(jb));
+        }
+        cv.notify_all();
+    };
+    auto begin_job = [&](Job& jb) {
+        {   // the device with the fewest batches in flight; wait while every slot everywhere is taken
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return *std::min_element(inflight.begin(), inflight.end()) < 3; });
+            jb.dev = (size_t)(std::min_element(inflight.begin(), inflight.end()) - inflight.begin());
+            ++inflight[jb.dev];
+        }
+        jb.batch = hm_batch_begin(eng[jb.dev]);
+        if (!jb.batch) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(eng[jb.dev])); failed = true; }
+    };
     int cur = 0;
     produce(nb[0]);
     while (!failed) {
@@ -270,32 +359,27 @@ int cmd_call(int argc, char** argv) {
         std::thread producer;
         if (!bt.eof) producer = std::thread(produce, std::ref(nb[cur ^ 1]));
         if (!bt.recs.empty()) {
-            Slot& sl = slots[b % slots.size()];
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !sl.active; });  // the consumer is done with this engine's previous batch
-            }
-            if (!failed) {
-                sl.recs = std::move(bt.recs);
-                bt.recs.clear();
-                for (size_t i = 0; i < sl.recs.size(); ++i) {
-                    const BamRecord& r = sl.recs[i];
-                    const KineticsView kv = kinetics_of(r);
-                    const int rc = hm_submit_read(sl.eng, (int32_t)i, r.l_qseq(), r.flag(), r.seq4(), kv.arr[0], kv.width[0],
-                                                  kv.arr[1], kv.width[1], kv.arr[2], kv.width[2], kv.arr[3], kv.width[3]);
-                    if (rc < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(sl.eng)); failed = true; break; }
+            Job jb;
+            begin_job(jb);
+            for (size_t i = 0; i < bt.recs.size() && !failed; ++i) {
+                BamRecord& r = bt.recs[i];
+                const KineticsView kv = kinetics_of(r);
+                int rc = hm_batch_submit_read(jb.batch, (int32_t)jb.recs.size(), r.l_qseq(), r.flag(), r.seq4(), kv.arr[0], kv.width[0],
+                                              kv.arr[1], kv.width[1], kv.arr[2], kv.width[2], kv.arr[3], kv.width[3]);
+                if (rc == HM_ENOMEM) {  // the slot is full (2^31 bases): queue it and go on in a fresh one
+                    launch(std::move(jb));
+                    jb = Job();
+                    begin_job(jb);
+                    if (failed) break;
+                    rc = hm_batch_submit_read(jb.batch, 0, r.l_qseq(), r.flag(), r.seq4(), kv.arr[0], kv.width[0], kv.arr[1],
+                                              kv.width[1], kv.arr[2], kv.width[2], kv.arr[3], kv.width[3]);
                 }
-                if (!failed && hm_flush(sl.eng) < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(sl.eng)); failed = true; }
-                if (!failed) {
-                    {
-                        std::lock_guard<std::mutex> lk(mu);
-                        sl.active = true;
-                        ready.push_back(b % slots.size());
-                    }
-                    cv.notify_all();
-                    ++b;
-                }
+                if (rc < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(eng[jb.dev])); failed = true; break; }
+                jb.recs.push_back(std::move(r));
             }
+            bt.recs.clear();
+            if (!failed) launch(std::move(jb));
+            else if (jb.batch) hm_batch_release(jb.batch);
         }
         if (producer.joinable()) producer.join();
         if (bt.eof) break;
@@ -307,7 +391,7 @@ int cmd_call(int argc, char** argv) {
     }
     cv.notify_all();
     writer.join();
-    for (auto& sl : slots) hm_destroy(sl.eng);
+    for (auto* e : eng) hm_destroy(e);
     if (failed) return EXIT_FAILURE;
     if (!out.close()) { fprintf(stderr, "[%s] %s: %s\n", kName, o.out.c_str(), out.error().c_str()); return EXIT_FAILURE; }
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -319,19 +403,121 @@ int cmd_call(int argc, char** argv) {
     return 0;
 }
 
+// bamcopy [-R r/w] IN.bam OUT.bam : BGZF/BAM round trip (of this rank's shard)
 int cmd_bamcopy(int argc, char** argv) {
-    if (argc != 4) { usage(); return EXIT_FAILURE; }
-    BgzfReader in(argv[2], 4);
+    Shard sh;
+    int a = 2;
+    if (argc >= 6 && std::string(argv[2]) == "-R") {
+        if (!parse_shard(argv[3], sh)) { usage(); return EXIT_FAILURE; }
+        a = 4;
+    }
+    if (argc - a != 2) { usage(); return EXIT_FAILURE; }
+    BgzfReader in(argv[a], 4);
     BamHeader h;
     std::string err;
-    if (!in.ok() || !read_header(in, h, err)) { fprintf(stderr, "%s%s\n", in.error().c_str(), err.c_str()); return EXIT_FAILURE; }
-    BgzfWriter out(argv[3], 4, 6);
+    int64_t end_off = 0;
+    if (!in.ok() || !open_shard(in, argv[a], sh, h, end_off, err)) { fprintf(stderr, "%s%s\n", in.error().c_str(), err.c_str()); return EXIT_FAILURE; }
+    BgzfWriter out(shard_path(argv[a + 1], sh), 4, 6);
     if (!out.ok()) return EXIT_FAILURE;
-    write_header(out, h);
+    if (sh.rank == 0) write_header(out, h);
     BamRecord r;
-    while (read_record(in, r, err)) write_record(out, r);
+    size_t n = 0;
+    while (end_off >= 0 && in.block_offset() < end_off && read_record(in, r, err)) {
+        write_record(out, r);
+        ++n;
+    }
     if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return EXIT_FAILURE; }
+    fprintf(stderr, "[%s] bamcopy: rank %d/%d wrote %zu records\n", kName, sh.rank, sh.world, n);
     return out.close() ? 0 : EXIT_FAILURE;
+}
+
+// merge OUT.bam N : joins OUT.bam.shard0 .. shard<N-1> in rank order.  A BGZF file is a series of independent gzip members,
+// so the shards are concatenated as they are, minus the 28-byte end-of-file marker of all but the last.
+int cmd_merge(int argc, char** argv) {
+    if (argc != 4) { usage(); return EXIT_FAILURE; }
+    const std::string out = argv[2];
+    const int n = atoi(argv[3]);
+    if (n < 1) { usage(); return EXIT_FAILURE; }
+    FILE* fo = fopen(out.c_str(), "wb");
+    if (!fo) { fprintf(stderr, "[%s] cannot create %s\n", kName, out.c_str()); return EXIT_FAILURE; }
+    std::vector<char> buf(size_t(8) << 20);
+    for (int r = 0; r < n; ++r) {
+        const std::string sp = out + ".shard" + std::to_string(r);
+        FILE* fi = fopen(sp.c_str(), "rb");
+        if (!fi) { fprintf(stderr, "[%s] cannot open %s\n", kName, sp.c_str()); fclose(fo); return EXIT_FAILURE; }
+        fseeko(fi, 0, SEEK_END);
+        int64_t left = (int64_t)ftello(fi) - (r + 1 < n ? 28 : 0);
+        fseeko(fi, 0, SEEK_SET);
+        while (left > 0) {
+            const size_t want = (size_t)std::min<int64_t>(left, (int64_t)buf.size());
+            if (fread(buf.data(), 1, want, fi) != want || fwrite(buf.data(), 1, want, fo) != want) {
+                fprintf(stderr, "[%s] i/o error on %s\n", kName, sp.c_str());
+                fclose(fi);
+                fclose(fo);
+                return EXIT_FAILURE;
+            }
+            left -= (int64_t)want;
+        }
+        fclose(fi);
+    }
+    if (fclose(fo) != 0) return EXIT_FAILURE;
+    for (int r = 0; r < n; ++r) remove((out + ".shard" + std::to_string(r)).c_str());
+    return 0;
+}
+
+// stagebench [-t N] [-R r/w] IN.bam : the host side of `call` without a GPU -- BGZF inflate, record parsing and the copy
+// of SEQ + kinetics into a staging slab exactly as hm_submit_read lays it out (plain memory instead of pinned).  Prints the
+// rate one rank's host side sustains: what has to exceed the GPU's appetite for the device to stay busy.
+int cmd_stagebench(int argc, char** argv) {
+    int threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    Shard sh;
+    int a = 2;
+    while (a + 1 < argc && argv[a][0] == '-') {
+        if (std::string(argv[a]) == "-t") threads = std::max(1, atoi(argv[a + 1]));
+        else if (std::string(argv[a]) == "-R") { if (!parse_shard(argv[a + 1], sh)) { usage(); return EXIT_FAILURE; } }
+        else { usage(); return EXIT_FAILURE; }
+        a += 2;
+    }
+    if (argc - a != 1) { usage(); return EXIT_FAILURE; }
+    // the staging slab exists before the clock starts (the engine's pinned slabs are allocated once and reused)
+    const size_t slab_bytes = size_t(256) << 20;
+    uint8_t* slab = static_cast<uint8_t*>(malloc(slab_bytes));
+    if (!slab) return EXIT_FAILURE;
+    memset(slab, 0, slab_bytes);
+    const auto t0 = std::chrono::steady_clock::now();
+    BgzfReader in(argv[a], threads);
+    BamHeader h;
+    std::string err;
+    int64_t end_off = 0;
+    if (!in.ok() || !open_shard(in, argv[a], sh, h, end_off, err)) { fprintf(stderr, "%s%s\n", in.error().c_str(), err.c_str()); return EXIT_FAILURE; }
+    const int64_t first_off = in.block_offset();
+    size_t fill = 0, reads = 0, staged = 0, bases = 0, bytes_staged = 0;
+    BamRecord r;
+    auto put = [&](const void* src, size_t n) {
+        const size_t al = (n + 15) & ~size_t(15);
+        if (fill + al > slab_bytes) fill = 0;  // a full slab would be handed to the device here
+        memcpy(slab + fill, src, n);
+        fill += al;
+        bytes_staged += n;
+    };
+    while (end_off >= 0 && in.block_offset() < end_off && read_record(in, r, err)) {
+        ++reads;
+        const KineticsView kv = kinetics_of(r);
+        const size_t L = (size_t)r.l_qseq();
+        if (L < 1000 || !kv.arr[0] || !kv.arr[1] || !kv.arr[2] || !kv.arr[3]) continue;
+        put(r.seq4(), (L + 1) / 2);
+        for (int k = 0; k < 4; ++k) put(kv.arr[k], L * (size_t)kv.width[k]);
+        ++staged;
+        bases += L;
+    }
+    if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return EXIT_FAILURE; }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const int64_t comp = in.block_offset() - first_off;
+    printf("{\"rank\": %d, \"world\": %d, \"threads\": %d, \"reads\": %zu, \"staged_reads\": %zu, \"bases\": %zu, \"seconds\": %.3f, "
+           "\"bam_MB_per_s\": %.1f, \"staged_MB_per_s\": %.1f, \"Mbases_per_s\": %.1f}\n",
+           sh.rank, sh.world, threads, reads, staged, bases, sec, (double)comp / sec / 1e6, (double)bytes_staged / sec / 1e6,
+           (double)bases / sec / 1e6);
+    return 0;
 }
 
 int cmd_tagtest(int argc, char** argv) {
@@ -421,6 +607,8 @@ int main(int argc, char** argv) {
     const std::string cmd = argv[1];
     if (cmd == "call") return cmd_call(argc, argv);
     if (cmd == "bamcopy") return cmd_bamcopy(argc, argv);
+    if (cmd == "merge") return cmd_merge(argc, argv);
+    if (cmd == "stagebench") return cmd_stagebench(argc, argv);
     if (cmd == "tagtest") return cmd_tagtest(argc, argv);
     if (cmd == "modstats") return cmd_modstats(argc, argv);
     if (cmd == "pileup") return cmd_pileup(argc, argv);

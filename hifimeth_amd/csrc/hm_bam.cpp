@@ -41,13 +41,6 @@ constexpr int BATCH_BLOCKS = 256;
 const uint8_t kEofBlock[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43,
                                0x02, 0x00, 0x1b, 0x00, 0x03, 0x00, 0, 0, 0, 0, 0, 0, 0, 0};
 
-struct RawBlock {
-    std::vector<uint8_t> comp;  // deflate payload
-    uint32_t crc = 0, isize = 0;
-    std::vector<uint8_t> out;
-    bool bad = false;
-};
-
 }  // namespace
 
 void parallel_run(int n, int threads, const std::function<void(int)>& f) { parallel_for(n, threads, f); }
@@ -55,101 +48,295 @@ void parallel_run(int n, int threads, const std::function<void(int)>& f) { paral
 // ------------------------------------------------------------------------------------------------
 // BGZF
 // ------------------------------------------------------------------------------------------------
-BgzfReader::BgzfReader(const std::string& path, int threads) : threads_(threads) {
+BgzfReader::BgzfReader(const std::string& path, int threads) : threads_(std::max(1, threads)) {
     fp_ = fopen(path.c_str(), "rb");
-    if (!fp_) err_ = "cannot open " + path;
+    if (!fp_) {
+        err_ = "cannot open " + path;
+        return;
+    }
+    start_prefetch();
 }
 
 BgzfReader::~BgzfReader() {
+    if (bg_) {
+        static_cast<std::thread*>(bg_)->join();
+        delete static_cast<std::thread*>(bg_);
+    }
     if (fp_) fclose(fp_);
 }
 
-bool BgzfReader::refill() {
-    std::vector<RawBlock> blocks;
-    while ((int)blocks.size() < BATCH_BLOCKS) {
+void BgzfReader::load(Chunk& c, int64_t from) {
+    c.data.clear();
+    c.segs.clear();
+    c.err.clear();
+    c.eof = false;
+    c.next_off = from;
+    struct Blk {
+        std::vector<uint8_t> comp;
+        uint32_t crc, isize;
+        size_t at;
+        int64_t off;
+    };
+    std::vector<Blk> blocks;
+    size_t total = 0;
+    if (fseeko(fp_, (off_t)from, SEEK_SET) != 0) {
+        c.err = "seek failed";
+        return;
+    }
+    while ((int)blocks.size() < 2 * BATCH_BLOCKS) {
         uint8_t hdr[12];
         const size_t got = fread(hdr, 1, 12, fp_);
         if (got == 0) {
-            eof_ = true;
+            c.eof = true;
             break;
         }
         if (got != 12 || hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) {
-            err_ = "not a BGZF file (bad gzip member header)";
-            return false;
+            c.err = "not a BGZF file (bad gzip member header)";
+            return;
         }
         const int xlen = rd16(hdr + 10);
-        std::vector<uint8_t> extra((size_t)xlen);
-        if (fread(extra.data(), 1, (size_t)xlen, fp_) != (size_t)xlen) {
-            err_ = "truncated BGZF block";
-            return false;
+        uint8_t extra[256];
+        if (xlen > (int)sizeof extra || fread(extra, 1, (size_t)xlen, fp_) != (size_t)xlen) {
+            c.err = "truncated BGZF block";
+            return;
         }
         int bsize = -1;
         for (int i = 0; i + 4 <= xlen;) {
-            const int slen = rd16(extra.data() + i + 2);
-            if (extra[(size_t)i] == 'B' && extra[(size_t)i + 1] == 'C' && slen == 2) bsize = rd16(extra.data() + i + 4);
+            const int slen = rd16(extra + i + 2);
+            if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2) bsize = rd16(extra + i + 4);
             i += 4 + slen;
         }
         if (bsize < 0) {
-            err_ = "BGZF block without BC field";
-            return false;
+            c.err = "BGZF block without BC field";
+            return;
         }
         const long clen = (long)bsize + 1 - 12 - xlen - 8;
         if (clen < 0) {
-            err_ = "corrupt BGZF block size";
-            return false;
+            c.err = "corrupt BGZF block size";
+            return;
         }
-        RawBlock b;
+        Blk b;
         b.comp.resize((size_t)clen);
         uint8_t tail[8];
         if (fread(b.comp.data(), 1, (size_t)clen, fp_) != (size_t)clen || fread(tail, 1, 8, fp_) != 8) {
-            err_ = "truncated BGZF block";
-            return false;
+            c.err = "truncated BGZF block";
+            return;
         }
         b.crc = rd32(tail);
         b.isize = rd32(tail + 4);
+        if (b.isize > 0x10000) {
+            c.err = "corrupt BGZF block (ISIZE)";
+            return;
+        }
+        b.at = total;
+        b.off = c.next_off;
+        total += b.isize;
+        c.next_off += (int64_t)bsize + 1;
         blocks.push_back(std::move(b));
     }
+    c.data.resize(total);
+    std::atomic<bool> bad{false};
     parallel_for((int)blocks.size(), threads_, [&](int i) {
-        RawBlock& b = blocks[(size_t)i];
-        b.out.resize(b.isize);
+        Blk& b = blocks[(size_t)i];
         if (b.isize == 0) return;
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit2(&zs, -15) != Z_OK) {
-            b.bad = true;
+            bad = true;
             return;
         }
         zs.next_in = b.comp.data();
         zs.avail_in = (uInt)b.comp.size();
-        zs.next_out = b.out.data();
-        zs.avail_out = (uInt)b.out.size();
+        zs.next_out = c.data.data() + b.at;
+        zs.avail_out = (uInt)b.isize;
         const int rc = inflate(&zs, Z_FINISH);
         inflateEnd(&zs);
-        if (rc != Z_STREAM_END || zs.total_out != b.isize || crc32(0L, b.out.data(), (uInt)b.out.size()) != b.crc) b.bad = true;
+        if (rc != Z_STREAM_END || zs.total_out != b.isize || crc32(0L, c.data.data() + b.at, (uInt)b.isize) != b.crc) bad = true;
     });
-    buf_.erase(buf_.begin(), buf_.begin() + (long)pos_);
-    pos_ = 0;
-    for (auto& b : blocks) {
-        if (b.bad) {
-            err_ = "BGZF block failed to inflate (corrupt data or CRC mismatch)";
-            return false;
-        }
-        buf_.insert(buf_.end(), b.out.begin(), b.out.end());
+    if (bad) {
+        c.err = "BGZF block failed to inflate (corrupt data or CRC mismatch)";
+        return;
     }
+    for (auto& b : blocks)
+        if (b.isize) c.segs.emplace_back(b.at, b.off);
+}
+
+void BgzfReader::start_prefetch() {
+    const int64_t from = nxt_.next_off;
+    bg_ = new std::thread([this, from] { load(nxt_, from); });
+}
+
+bool BgzfReader::advance(bool append) {
+    if (!bg_) return false;  // nothing more to read
+    static_cast<std::thread*>(bg_)->join();
+    delete static_cast<std::thread*>(bg_);
+    bg_ = nullptr;
+    if (!nxt_.err.empty()) {
+        err_ = nxt_.err;
+        return false;
+    }
+    const bool was_eof = nxt_.eof;
+    if (append) {
+        // keep the unread part of the current chunk in front (a record, or the peek window, spans the chunk boundary)
+        size_t keep = 0;
+        while (keep + 1 < cur_.segs.size() && cur_.segs[keep + 1].first <= pos_) ++keep;
+        cur_.segs.erase(cur_.segs.begin(), cur_.segs.begin() + (long)keep);
+        for (auto& sg : cur_.segs) sg.first = sg.first >= pos_ ? sg.first - pos_ : 0;
+        if (pos_ >= cur_.data.size()) cur_.segs.clear();
+        cur_.data.erase(cur_.data.begin(), cur_.data.begin() + (long)std::min(pos_, cur_.data.size()));
+        pos_ = 0;
+        const size_t base = cur_.data.size();
+        for (auto& sg : nxt_.segs) cur_.segs.emplace_back(base + sg.first, sg.second);
+        cur_.data.insert(cur_.data.end(), nxt_.data.begin(), nxt_.data.end());
+        cur_.next_off = nxt_.next_off;
+    } else {
+        std::swap(cur_, nxt_);
+        nxt_.next_off = cur_.next_off;
+        pos_ = 0;
+    }
+    cur_.eof = was_eof;
+    nxt_.next_off = cur_.next_off;
+    if (!was_eof) start_prefetch();
     return true;
 }
 
 bool BgzfReader::read(void* dst, size_t n) {
-    while (buf_.size() - pos_ < n) {
-        if (eof_) {
-            if (buf_.size() - pos_ != 0 && err_.empty()) err_ = "truncated file";
+    uint8_t* d = static_cast<uint8_t*>(dst);
+    size_t done = 0;
+    while (done < n) {
+        const size_t avail = cur_.data.size() - pos_;
+        if (avail == 0) {
+            if (!advance(false)) {
+                if (done != 0 && err_.empty()) err_ = "truncated file";
+                return false;
+            }
+            continue;
+        }
+        const size_t take = std::min(avail, n - done);
+        memcpy(d + done, cur_.data.data() + pos_, take);
+        pos_ += take;
+        done += take;
+    }
+    return true;
+}
+
+bool BgzfReader::seek_block(int64_t file_offset) {
+    if (!fp_) return false;
+    if (bg_) {
+        static_cast<std::thread*>(bg_)->join();
+        delete static_cast<std::thread*>(bg_);
+        bg_ = nullptr;
+    }
+    cur_ = Chunk();
+    nxt_ = Chunk();
+    pos_ = 0;
+    cur_.next_off = nxt_.next_off = file_offset;
+    err_.clear();
+    start_prefetch();
+    return true;
+}
+
+int64_t BgzfReader::block_offset() const {
+    if (pos_ >= cur_.data.size()) return cur_.next_off;
+    int64_t off = cur_.segs.empty() ? cur_.next_off : cur_.segs.front().second;
+    for (const auto& sg : cur_.segs) {
+        if (sg.first > pos_) break;
+        off = sg.second;
+    }
+    return off;
+}
+
+size_t BgzfReader::peek(const uint8_t*& p, size_t want) {
+    while (cur_.data.size() - pos_ < want) {
+        if (!advance(true)) break;
+    }
+    p = cur_.data.data() + pos_;
+    return std::min(want, cur_.data.size() - pos_);
+}
+
+void BgzfReader::skip(size_t n) { pos_ = std::min(cur_.data.size(), pos_ + n); }
+
+bool scan_bgzf_blocks(const std::string& path, std::vector<int64_t>& offsets, int64_t& file_size, std::string& err) {
+    FILE* fp = fopen(path.c_str(), "rb");
+    if (!fp) {
+        err = "cannot open " + path;
+        return false;
+    }
+    offsets.clear();
+    int64_t at = 0;
+    for (;;) {
+        uint8_t hdr[18];
+        if (fseeko(fp, (off_t)at, SEEK_SET) != 0) break;
+        const size_t got = fread(hdr, 1, 18, fp);
+        if (got == 0) break;
+        // every writer in use (htslib, this one) puts the BC subfield first: 12-byte gzip header, XLEN 6, 'B' 'C' 2 BSIZE
+        if (got != 18 || hdr[0] != 0x1f || hdr[1] != 0x8b || rd16(hdr + 10) != 6 || hdr[12] != 'B' || hdr[13] != 'C') {
+            err = "not a BGZF file (or a BGZF dialect with extra subfields)";
+            fclose(fp);
             return false;
         }
-        if (!refill()) return false;
+        offsets.push_back(at);
+        at += (int64_t)rd16(hdr + 16) + 1;
     }
-    memcpy(dst, buf_.data() + pos_, n);
-    pos_ += n;
+    file_size = at;
+    fclose(fp);
     return true;
+}
+
+static bool plausible_record(const uint8_t* p, size_t avail, int n_ref, size_t& total, bool& complete) {
+    complete = false;
+    if (avail < 36) return false;
+    const uint32_t bs = rd32(p);
+    if (bs < 34 || bs > (1u << 28)) return false;
+    const int32_t ref = (int32_t)rd32(p + 4), pos = (int32_t)rd32(p + 8);
+    const int l_name = p[12], n_cig = rd16(p + 16);
+    const int32_t l_seq = (int32_t)rd32(p + 20), nref = (int32_t)rd32(p + 24), npos = (int32_t)rd32(p + 28);
+    if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos < -1 || npos < -1) return false;
+    if (l_name < 2 || l_seq < 0 || l_seq > (1 << 28)) return false;
+    const size_t fixed = 32 + (size_t)l_name + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    if (fixed > bs) return false;
+    total = 4 + (size_t)bs;
+    const size_t name_end = 4 + 32 + (size_t)l_name;
+    if (avail < name_end) return true;  // cannot look further: not contradicted
+    for (size_t i = 36; i + 1 < name_end; ++i)
+        if (p[i] < 33 || p[i] > 126) return false;
+    if (p[name_end - 1] != 0) return false;
+    if (avail < total) return true;
+    const uint8_t* a = p + 4 + fixed;
+    const uint8_t* end = p + total;
+    AuxField f;
+    while (a < end)
+        if (!next_aux(a, end, f)) return false;
+    complete = a == end;
+    return complete;
+}
+
+bool find_record_start(BgzfReader& in, int n_ref, std::string& err) {
+    const uint8_t* p;
+    const size_t avail = in.peek(p, size_t(16) << 20);
+    if (!in.error().empty()) {
+        err = in.error();
+        return false;
+    }
+    for (size_t o = 0; o + 36 <= avail; ++o) {
+        size_t at = o;
+        int ok = 0;
+        bool good = true;
+        while (ok < 4 && at + 36 <= avail) {  // the candidate and up to three records behind it
+            size_t total;
+            bool complete;
+            if (!plausible_record(p + at, avail - at, n_ref, total, complete)) { good = false; break; }
+            if (!complete) break;  // ran out of buffered data: not contradicted
+            ++ok;
+            at += total;
+        }
+        if (good && ok >= 1) {
+            in.skip(o);
+            return true;
+        }
+    }
+    in.skip(avail);
+    return false;
 }
 
 BgzfWriter::BgzfWriter(const std::string& path, int threads, int level) : threads_(threads), level_(level) {

@@ -18,6 +18,9 @@ namespace hmbam {
 // run f(0..n-1) on up to `threads` host threads (work-stealing counter); used for BGZF blocks and per-read tagging
 void parallel_run(int n, int threads, const std::function<void(int)>& f);
 
+// BGZF reader.  The file is consumed in chunks of up to 512 blocks: a background thread reads the next chunk's blocks and
+// inflates them on `threads` host threads -- each block straight into its final place, the places being known from the
+// blocks' ISIZE fields -- while the caller parses the current chunk, so inflate overlaps record parsing and staging.
 class BgzfReader {
 public:
     BgzfReader(const std::string& path, int threads);
@@ -26,16 +29,43 @@ public:
     const std::string& error() const { return err_; }
     // read exactly n bytes; returns false at clean EOF (0 bytes available) or on error (error() set)
     bool read(void* dst, size_t n);
+    // ---- reading a byte range of the file (one rank of a read-sharded job inflates only its own blocks) ----
+    // continue at the BGZF block that starts at compressed offset `file_offset` (buffered data is dropped)
+    bool seek_block(int64_t file_offset);
+    // compressed offset of the block that holds the next unread byte (the file size once everything is consumed)
+    int64_t block_offset() const;
+    // make up to `want` unread bytes available without consuming them; returns how many there are (fewer at EOF)
+    size_t peek(const uint8_t*& p, size_t want);
+    void skip(size_t n);  // consume n bytes that peek() has shown
 
 private:
-    bool refill();
+    struct Chunk {
+        std::vector<uint8_t> data;
+        std::vector<std::pair<size_t, int64_t>> segs;  // (first byte in data, compressed offset) of every non-empty block
+        int64_t next_off = 0;                          // compressed offset behind the chunk's last block
+        bool eof = false;
+        std::string err;
+    };
+    void load(Chunk& c, int64_t from);  // blocks starting at compressed offset `from` -> c (runs on the background thread)
+    void start_prefetch();
+    bool advance(bool append);          // next chunk becomes (or is appended to) the current one
     FILE* fp_ = nullptr;
     int threads_;
-    std::vector<uint8_t> buf_;
+    Chunk cur_, nxt_;
     size_t pos_ = 0;
-    bool eof_ = false;
+    void* bg_ = nullptr;  // std::thread of the prefetch in flight
     std::string err_;
 };
+
+// compressed offsets of all BGZF blocks of a file (header hop, nothing is inflated) + the file size
+bool scan_bgzf_blocks(const std::string& path, std::vector<int64_t>& offsets, int64_t& file_size, std::string& err);
+
+// Finds the first BAM record that starts at or after the reader's current position (a block boundary somewhere inside
+// the file) and consumes the bytes in front of it.  BAM has no sync marker: candidates are validated like Hadoop-BAM's
+// split guesser does -- fixed fields in range, printable NUL-terminated name, sizes that add up, aux fields that walk
+// exactly to the record's end -- and must be followed by further records that validate the same way.
+// Returns false with err empty if there is no record start before EOF.
+bool find_record_start(BgzfReader& in, int n_ref, std::string& err);
 
 class BgzfWriter {
 public:

@@ -146,7 +146,10 @@ struct hm_engine {
     int min_read_size = 1000;  // mod_options.cpp:10
     int64_t sub_batch = 65536;
     int front_waves = 8;
-    int precision = 1;  // 1 = split-half f16x3 MFMA with fp32 accumulate (default), 0 = fp32 MFMA
+    // 0 = fp32 MFMA; 1 = split-half f16x3 MFMA with fp32 accumulate (default); 2 = 1 with plain fp16 WEIGHTS in conv6..conv8
+    // (where they hold the 1e-3 bar of BASELINE.json configs[4]); 3 = fp16 weights in conv2..conv8 (the literal configs[4]:
+    // misses its bar, kept for the record)
+    int precision = 1;
     int max_slots = 3;  // batch slots of the asynchronous API (the legacy calls use one more, slot 0)
     int trunk = 1;      // 1 = conv1..conv4 once per read position (hm_trunk.hip), 0 = once per site (front kernels)
     int64_t group_bases = int64_t(2) << 20;  // reads per trunk group: their maps take ~3.9 KB per base
@@ -306,7 +309,7 @@ void launch_cnn_pair(hm_engine* e, std::vector<TimedSpan>* spans, int ctx, const
         Span sp(e, spans, K_FRONT, ctx, sr.off, sr.cap);
         if (e->precision >= 1)
             launch_front_h(e->stream, dm.k1, sr, reads, bases, kin, windows, dm.w, e->d_act4.as<float>(), e->num_cu, dbg,
-                           dbg_layer, e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr, e->precision == 2);
+                           dbg_layer, e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr, e->precision == 3);
         else
             launch_front(e->stream, dm.k1, sr, reads, bases, kin, windows, dm.w, e->d_act4.as<float>(), e->num_cu, dbg,
                          dbg_layer, e->front_waves, e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr);
@@ -317,7 +320,7 @@ void launch_cnn_pair(hm_engine* e, std::vector<TimedSpan>* spans, int ctx, const
         Span sp(e, spans, K_TAIL, ctx, sr.off, sr.cap);
         if (e->precision >= 1)
             launch_tail_h(e->stream, e->d_act4.as<float>(), sr, dm.w, logits, p, ml, e->num_cu, dbg, dbg_layer,
-                          e->precision == 2);
+                          e->precision - 1);
         else
             launch_tail(e->stream, e->d_act4.as<float>(), sr, dm.w, logits, p, ml, e->num_cu, dbg, dbg_layer);
         sp.end();
@@ -507,7 +510,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans) {
         e->d_zeros.reserve(256);
         HIP_TRY(hipMemsetAsync(e->d_zeros.p, 0, 256, e->stream));
     }
-    const bool w16 = e->precision == 2;
+    const bool w16 = e->precision == 3;
     const int32_t* offs = b->d_offs.as<int32_t>();
     for (const auto& g : b->groups) {
         const TrunkMaps maps{{e->d_map[0].as<uint16_t>(), e->d_map[1].as<uint16_t>(), e->d_map[2].as<uint16_t>()},
@@ -534,7 +537,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans) {
             {
                 Span sp(e, spans, K_TAILG, c);
                 launch_tail_gather(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
-                                   b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu, w16);
+                                   b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu, e->precision - 1);
                 sp.end();
             }
         }
@@ -709,7 +712,8 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
     if (k == "min_read_size") e->min_read_size = (int)value;
     else if (k == "timing") e->timing = value != 0;
     else if (k == "precision") {
-        if (value < 0 || value > 2) return fail(e, HM_EINVAL, "precision must be 0 (fp32), 1 (f16x3 split) or 2 (fp16 weights)");
+        if (value < 0 || value > 3)
+            return fail(e, HM_EINVAL, "precision must be 0 (fp32), 1 (f16x3 split), 2 (fp16 weights in conv6..conv8) or 3 (in conv2..conv8)");
         e->precision = (int)value;
     } else if (k == "stamps") {
         e->stamps_on = value != 0;

@@ -394,7 +394,10 @@ __device__ __forceinline__ void zero_pad_rows_h(half_t* hi, half_t* lo, int rs, 
 // the same 384 bytes as fp32), so the gather is a pure copy into the input planes: the spare waves of conv6 / conv7 /
 // conv8 issue it as LDS-DMA (global_load_lds_dwordx4: no VGPRs, no VALU split, no ds_write), one 1 KB piece of a plane per
 // wave instruction with a per-lane source address (a zero page for padding rows, row pads and sites past the end).
-template <bool W16, bool GATHER = false>
+// W16T: 0 = split (hi + lo) weights everywhere; 1 = plain fp16 weights in conv6..conv8 -- the part of the network where they hold
+// the |dp| <= 1e-3 bar of BASELINE.json configs[4] (tools/w16_error_table.py); 2 = also in conv5 (with conv2..conv4: the literal
+// configs[4], which misses its bar).  fc1 keeps split weights in every mode.
+template <int W16T, bool GATHER = false>
 __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ act4, SiteRange sr, CtxWeights W,
                                                       float* __restrict__ logits,
                                                       float* __restrict__ prob, uint8_t* __restrict__ ml,
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         }
         __syncthreads();  // input of group g staged (by the previous iteration's spare waves); s_row visible
 
-        ConvH<NW, 96, 3, 96, T::L5, T::RS96, 4, 2, 3, S, T::IN_SS, 0, !W16>::run(
+        ConvH<NW, 96, 3, 96, T::L5, T::RS96, 4, 2, 3, S, T::IN_SS, 0, (W16T < 2)>::run(
             h0, l0, wf(4), EpiPlanesS<T::L5, T::RS96, T::C5_SS>{h1, l1, W.bias[4]});
         zero_pad_rows_h<S, T::L5, 96>(h1, l1, T::RS96, T::C5_SS);
         __syncthreads();
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
                 for (int k = 0; k < NHI; ++k) fake_def(phi[k]);
             }
         } else {
-            ConvH<NW, 96, 3, 96, T::L6, T::RS96, 1, 6, 3, S, T::C5_SS, 0, !W16>::run(
+            ConvH<NW, 96, 3, 96, T::L6, T::RS96, 1, 6, 3, S, T::C5_SS, 0, (W16T < 1)>::run(
                 h1, l1, wf(5), EpiPlanesS<T::L6, T::RS96, T::C6_SS>{h0, l0, W.bias[5]});
 #pragma unroll
             for (int k = 0; k < NHI; ++k) fake_def(phi[k]);
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
                 for (int k = 0; k < NLO; ++k) fake_def(plo[k]);
             }
         } else {
-            ConvH<NW, 96, 3, 64, T::L7, T::RS96, 1, 4, 3, S, T::C6_SS, 0, !W16>::run(
+            ConvH<NW, 96, 3, 64, T::L7, T::RS96, 1, 4, 3, S, T::C6_SS, 0, (W16T < 1)>::run(
                 h0, l0, wf(6), EpiPlanesS<T::L7, T::RS64, T::C7_SS>{h1, l1, W.bias[6]});
 #pragma unroll
             for (int k = 0; k < NLO; ++k) fake_def(plo[k]);
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
                 zero_in_pads(0, SPLIT_SITE, tl - 256, 128);
             }
         } else {
-            ConvH<NW, 64, 3, 64, T::L8, T::RS64, 1, 4, 3, S, T::C7_SS, 0, !W16>::run(
+            ConvH<NW, 64, 3, 64, T::L8, T::RS64, 1, 4, 3, S, T::C7_SS, 0, (W16T < 1)>::run(
                 h1, l1, wf(7), EpiRing<T::L8, T::RS64>{r_hi + slot * S * T::RING_SS, r_lo + slot * S * T::RING_SS, W.bias[7]});
         }
         if (slot == 0) g_first = g;
@@ -689,29 +692,26 @@ static int cnn_grid_h(const SiteRange& sr, int per_group, int grid) {
 }
 
 void launch_tail_h(hipStream_t st, const float* act4, const SiteRange& sr, const CtxWeights& w, float* logits,
-                   float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer, bool w16) {
+                   float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer, int w16) {
     if (sr.cap <= 0) return;
     const dim3 g(cnn_grid_h(sr, TAIL_SITES, grid));
-    if (w16)
-        hipLaunchKernelGGL((tail_kernel_h<true, false>), g, dim3(512), 0, st, act4, sr, w, logits, p, ml, dbg, dbg_layer,
-                           nullptr, nullptr, nullptr, nullptr);
-    else
-        hipLaunchKernelGGL((tail_kernel_h<false, false>), g, dim3(512), 0, st, act4, sr, w, logits, p, ml, dbg, dbg_layer,
-                           nullptr, nullptr, nullptr, nullptr);
+#define HM_TAILA(LV)                                                                                                  \
+    hipLaunchKernelGGL((tail_kernel_h<LV, false>), g, dim3(512), 0, st, act4, sr, w, logits, p, ml, dbg, dbg_layer, \
+                       nullptr, nullptr, nullptr, nullptr)
+    if (w16 >= 2) HM_TAILA(2); else if (w16 == 1) HM_TAILA(1); else HM_TAILA(0);
+#undef HM_TAILA
 }
 
 void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
-                        const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, bool w16) {
+                        const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, int w16) {
     if (sr.cap <= 0) return;
     const dim3 g(cnn_grid_h(sr, TAIL_SITES, grid));
-    if (w16)
-        hipLaunchKernelGGL((tail_kernel_h<true, true>), g, dim3(512), 0, st, nullptr, sr, w, logits, p, ml, nullptr, 0,
-                           reinterpret_cast<const half_t*>(maps.e4), reinterpret_cast<const half_t*>(edge4), e4row,
-                           reinterpret_cast<const half_t*>(maps.zeros));
-    else
-        hipLaunchKernelGGL((tail_kernel_h<false, true>), g, dim3(512), 0, st, nullptr, sr, w, logits, p, ml, nullptr, 0,
-                           reinterpret_cast<const half_t*>(maps.e4), reinterpret_cast<const half_t*>(edge4), e4row,
-                           reinterpret_cast<const half_t*>(maps.zeros));
+#define HM_TAILG(LV)                                                                                                     \
+    hipLaunchKernelGGL((tail_kernel_h<LV, true>), g, dim3(512), 0, st, nullptr, sr, w, logits, p, ml, nullptr, 0,         \
+                       reinterpret_cast<const half_t*>(maps.e4), reinterpret_cast<const half_t*>(edge4), e4row,          \
+                       reinterpret_cast<const half_t*>(maps.zeros))
+    if (w16 >= 2) HM_TAILG(2); else if (w16 == 1) HM_TAILG(1); else HM_TAILG(0);
+#undef HM_TAILG
 }
 
 void launch_front_h(hipStream_t st, int k1, const SiteRange& sr, const ReadDesc* reads, const uint8_t* bases,

@@ -40,7 +40,7 @@ void launch_front_h(hipStream_t st, int k1, const SiteRange& sr, const ReadDesc*
                     const uint32_t* kin, const float* windows, const CtxWeights& w, float* act4, int grid, float* dbg,
                     int dbg_layer, unsigned long long* stamps, bool w16);
 void launch_tail_h(hipStream_t st, const float* act4, const SiteRange& sr, const CtxWeights& w, float* logits,
-                   float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer, bool w16);
+                   float* p, uint8_t* ml, int grid, float* dbg, int dbg_layer, int w16_level);
 // tail: conv5..conv8, fc1, fc2, softmax for 8 sites per workgroup pass.
 // results go to index sites[i].uidx (or i when sites == nullptr).
 void launch_tail(hipStream_t st, const float* act4, const SiteRange& sr, const CtxWeights& w, float* logits,
@@ -70,7 +70,7 @@ void launch_edge(hipStream_t st, int k1, const SiteRange& sr, const RInfo* rinfo
                  const uint32_t* kin, const CtxWeights& w, const TrunkMaps& maps, uint16_t* edge4, int32_t* e4row, int grid,
                  bool w16);
 void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
-                        const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, bool w16);
+                        const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, int w16_level);
 size_t trunk_lds_bytes();
 
 size_t front_lds_bytes(int k1);

@@ -88,8 +88,11 @@ void hm_destroy(hm_engine_t* e);
 const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a failed hm_create */
 /* options: "slots" (batches in flight of the hm_batch_* pipeline, default 3), "min_read_size" (-l, default 1000), "timing" (0/1), "sub_batch_sites" (front/tail
  * launch granularity, default 65536), "front_waves" (4 or 8 waves per front workgroup), "precision" (0 = fp32 MFMA, exact;
- * 1 = split-half fp16x3 MFMA with fp32 accumulate; 2 = fp16 WEIGHTS for conv2..conv8 (conv1 and fc1 keep split
- * weights), activations still split, fp32 accumulate: BASELINE.json configs[4], bar |dp| <= 1e-3), "stamps" (diagnostic) */
+ * 1 = split-half fp16x3 MFMA with fp32 accumulate (default); 2 = 1 with plain fp16 WEIGHTS in conv6..conv8, the part of the
+ * network where they hold BASELINE.json configs[4]'s bar |dp| <= 1e-3 (tools/w16_error_table.py); 3 = fp16 weights in
+ * conv2..conv8, the literal configs[4], which misses that bar (max |dp| ~ 2.5e-3): kept for the record; activations stay
+ * split and accumulation fp32 in every mode), "trunk" (1 = conv1..conv4 once per read position, default; 0 = once per
+ * site), "group_bases" (reads per trunk group, default 2 Mi bases), "stamps" (diagnostic) */
 int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
 
 /* ---- staging: the EvalKmerFeaturesGenerator::init seam ----------------------------------- */

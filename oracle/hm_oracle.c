@@ -248,10 +248,19 @@ void hmo_model_free(hmo_model_t* m) {
 
 int hmo_model_k1(const hmo_model_t* m) { return m->k[0]; }
 
-/* Conv1d(stride 2, padding 1) + bias + ReLU, channels-last in/out.  4 positions x 32 couts per register block. */
+/* Conv1d(stride 2, padding 1) + bias + ReLU, channels-last in/out.  PB positions x 32 couts per register block
+ * (AVX-512: 6 x 2 zmm accumulators, AVX2: 2 x 4 ymm); rows in the padding read a zero row instead of branching.
+ * Every output still accumulates bias, then tap 0 channel 0, 1, ... in the reference order: the blocking decides which
+ * outputs share a pass over the weights, not the order of anyone's additions, so results do not depend on it. */
+#if defined(__AVX512F__)
+enum { CONV_PB = 6 };
+#else
+enum { CONV_PB = 2 };
+#endif
 static void conv_s2_relu(const float* in, int Lin, int Cin, const float* wt, const float* bias, int k, int Cout,
                          float* out, int Lout) {
-    enum { PB = 4, CB = 32 };
+    enum { PB = CONV_PB, CB = 32 };
+    static const float zero_row[128] = {0};
     for (int p0 = 0; p0 < Lout; p0 += PB) {
         const int np = Lout - p0 < PB ? Lout - p0 : PB;
         for (int c0 = 0; c0 < Cout; c0 += CB) {
@@ -262,12 +271,12 @@ static void conv_s2_relu(const float* in, int Lin, int Cin, const float* wt, con
                 const float* x[PB];
                 for (int j = 0; j < PB; ++j) {
                     const int row = 2 * (p0 + j) - 1 + t; /* padding = 1 */
-                    x[j] = (j < np && row >= 0 && row < Lin) ? in + (size_t)row * Cin : NULL;
+                    x[j] = (j < np && row >= 0 && row < Lin) ? in + (size_t)row * Cin : zero_row;
                 }
                 const float* w = wt + (size_t)t * Cin * Cout + c0;
                 for (int c = 0; c < Cin; ++c, w += Cout) {
+#pragma GCC unroll 8
                     for (int j = 0; j < PB; ++j) {
-                        if (!x[j]) continue;
                         const float xv = x[j][c];
 #pragma omp simd
                         for (int o = 0; o < CB; ++o) acc[j][o] += xv * w[o];

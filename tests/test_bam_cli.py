@@ -108,6 +108,38 @@ def test_tag_writer_reverse_flag_read(tmp_path, oracle, oracle_models):
     assert tags["MM"][2] == want["MM"] and np.array_equal(tags["ML"][2], want["ML"])
 
 
+def test_tag_writer_literal_known_answers(tmp_path):
+    """MM / ML / MN strings worked out by hand from build_mod_bam.cpp:134-176 (tests/golden/modtags_known_answers.json):
+    the product's writer AND the restated rules (oracle/modtags.py) must both reproduce them, so the two cannot drift
+    together.  (The reference's own tag code needs htslib and holds no fixtures: parity is otherwise unpinned here.)"""
+    import json
+    from oracle.modtags import expected_tags
+    from hifimeth_amd.synth import read_from_ascii
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "modtags_known_answers.json")))["cases"]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads, calls = [], []
+    for i, c in enumerate(cases):
+        seq = c["stored_seq"].encode()
+        L = len(seq)
+        k = np.zeros(L, np.uint8)
+        reads.append(read_from_ascii(seq, k, k, k, k, flag=c["flag"], name=c["name"]))
+        rec = np.zeros(len(c["calls"]), CALL_DTYPE)
+        for j, (q, st, ml) in enumerate(c["calls"]):
+            rec[j] = (i, q, st, 0, ml, 0, ml / 255.0)
+        calls.append(rec)
+        fwd = seq.translate(comp)[::-1] if c["flag"] & 16 else seq
+        want = expected_tags(fwd, rec["qoff"], rec["strand"], rec["scaled_prob"])
+        assert want["MM"] == c["MM"] and want["ML"].tolist() == c["ML"] and want["MN"] == c["MN"], c["name"]
+    src, dst, cb = str(tmp_path / "in.bam"), str(tmp_path / "out.bam"), str(tmp_path / "calls.bin")
+    bamutil.reads_to_bam(src, reads)
+    np.concatenate(calls).tofile(cb)
+    subprocess.check_call([CLI, "tagtest", src, cb, dst])
+    _, recs = bamutil.read_bam(dst)
+    for c, rec in zip(cases, recs):
+        d = {t[0]: t for t in bamutil.parse_aux(rec["aux"])}
+        assert d["MM"][2] == c["MM"] and d["ML"][2].tolist() == c["ML"] and d["MN"][2] == c["MN"], c["name"]
+
+
 def test_tag_writer_rejects_unsorted_calls(tmp_path, oracle, oracle_models):
     reads = _reads()
     calls = _oracle_calls(oracle, oracle_models, reads)
@@ -143,6 +175,29 @@ def test_cli_call_end_to_end(tmp_path, oracle, oracle_models, ctx, mask):
         assert np.abs(tags["ML"][2].astype(int) - want["ML"].astype(int)).max() <= 1
         called += 1
     assert called >= 15
+
+
+@pytest.mark.gpu
+def test_cli_call_sharded_over_ranks_matches_single_rank(tmp_path):
+    """`call -R r/w`: two ranks (run one after the other on this box's one GPU) each call their byte range of the input;
+    the merged BAM holds exactly the records of the single-rank run, in input order, and `-h` / `-v` exit 0
+    (mod_options.cpp:62-71)."""
+    reads = synth_reads(30, seed=61, median_len=4000, sigma=0.5, frac_wide=0.1, frac_short=0.1, frac_missing=0.1)
+    src, one, two = str(tmp_path / "in.bam"), str(tmp_path / "one.bam"), str(tmp_path / "two.bam")
+    bamutil.reads_to_bam(src, reads, level=1)
+    subprocess.check_call([CLI, "call", "-b", "9", "-t", "4", src, one], stderr=subprocess.DEVNULL)
+    for r in range(2):
+        subprocess.check_call([CLI, "call", "-b", "9", "-t", "4", "-R", f"{r}/2", src, two], stderr=subprocess.DEVNULL)
+    subprocess.check_call([CLI, "merge", two, "2"])
+    _, a = bamutil.read_bam(one)
+    _, b = bamutil.read_bam(two)
+    assert len(a) == len(b) == len(reads)
+    for x, y in zip(a, b):
+        assert x["name"] == y["name"] and x["aux"] == y["aux"] and np.array_equal(x["seq4"], y["seq4"])
+    assert sum(1 for x in a if b"MM" in x["aux"]) >= 15
+    assert subprocess.call([CLI, "call", "-h"], stderr=subprocess.DEVNULL) == 0
+    assert subprocess.call([CLI, "call", "-v"], stderr=subprocess.DEVNULL) == 0
+    assert subprocess.call([CLI, "call", "--nonsense"], stderr=subprocess.DEVNULL) != 0
 
 
 def _modstats(path):

@@ -84,3 +84,73 @@ def test_two_rank_sharding_matches_single_process():
     assert (s1, t1) == (5.0, 0.5)
     g = D.gather_calls(None, [single[:3], single[3:]], [0, 1], 2, CALL_DTYPE)
     assert g.tobytes() == single.tobytes()
+
+
+def _payload(path):
+    """inflated content of a BGZF file (block layout aside, this is what two BAM files have to agree on)"""
+    import gzip
+    return gzip.open(path, "rb").read()
+
+
+def test_bgzf_offset_sharding_and_merge_is_identity(tmp_path):
+    """`-R r/w` splits the input by BGZF offset (a rank inflates only its own blocks and finds its first record without
+    an index); the shards joined in rank order must equal the single-rank output -- for 2, 3 and 7 ranks, on a file whose
+    ~50 KB records straddle block boundaries, and on a file with fewer records than ranks."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bamutil
+    from hifimeth_amd.synth import synth_reads
+    cli = os.path.join(ROOT, "hifimeth_amd", "bin", "hifimeth-hip")
+    for tag, reads in (("big", synth_reads(60, seed=8, median_len=9000, sigma=0.5, frac_short=0.1, frac_missing=0.1, frac_wide=0.2)),
+                       ("tiny", synth_reads(2, seed=9, median_len=1500, sigma=0.1))):
+        src, one = str(tmp_path / f"{tag}.bam"), str(tmp_path / f"{tag}.one.bam")
+        bamutil.reads_to_bam(src, reads, level=1)
+        subprocess.check_call([cli, "bamcopy", src, one], stderr=subprocess.DEVNULL)
+        want = _payload(one)
+        for world in (2, 3, 7):
+            out = str(tmp_path / f"{tag}.w{world}.bam")
+            counts = []
+            for r in range(world):
+                p = subprocess.run([cli, "bamcopy", "-R", f"{r}/{world}", src, out], capture_output=True, text=True)
+                assert p.returncode == 0, p.stderr
+                counts.append(int(p.stderr.split("wrote")[1].split()[0]))
+            assert sum(counts) == len(reads)
+            if tag == "big":
+                assert min(counts) > 0 and max(counts) < len(reads)          # every rank got a share
+            subprocess.check_call([cli, "merge", out, str(world)])
+            assert _payload(out) == want and not os.path.exists(out + ".shard0")
+
+
+def _copy_worker(rank, world, port, src, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, ROOT)
+    from hifimeth_amd import call_dist
+    rc = call_dist.run(["--copy", src, out], backend="gloo")
+    assert rc == 0
+
+
+def test_two_rank_call_driver_over_a_bam_file(tmp_path):
+    """hifimeth_amd.call_dist as the driver launches it (one process per rank, gloo here): each rank shards the BAM by
+    offset and runs the native front end as a child, rank 0 merges after the barrier; output = single-rank output."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bamutil
+    from hifimeth_amd.synth import synth_reads
+    cli = os.path.join(ROOT, "hifimeth_amd", "bin", "hifimeth-hip")
+    reads = synth_reads(40, seed=18, median_len=6000, sigma=0.4)
+    src, one, out = str(tmp_path / "in.bam"), str(tmp_path / "one.bam"), str(tmp_path / "two.bam")
+    bamutil.reads_to_bam(src, reads, level=1)
+    subprocess.check_call([cli, "bamcopy", src, one], stderr=subprocess.DEVNULL)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_copy_worker, args=(r, 2, port, src, out)) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    assert _payload(out) == _payload(one)

@@ -146,7 +146,7 @@ def test_windows_golden_reference_python(mc):
         mc.clear()
 
 
-@pytest.mark.parametrize("ctx,name", [(0, "CpG"), (2, "CHH")])
+@pytest.mark.parametrize("ctx,name", [(0, "CpG"), (1, "CHG"), (2, "CHH")])
 def test_cnn_layers_vs_oracle(mc, oracle, ctx, name):
     z = np.load(os.path.join(GOLDEN, f"cnn_{name}.npz"))
     om = oracle.Model(os.path.join(WEIGHTS, name + ".hmw"))
@@ -160,7 +160,7 @@ def test_cnn_layers_vs_oracle(mc, oracle, ctx, name):
             assert err <= 1e-4 * max(1.0, np.abs(want).max()), (name, widx, layer, err)
 
 
-@pytest.mark.parametrize("ctx,name", [(0, "CpG"), (2, "CHH")])
+@pytest.mark.parametrize("ctx,name", [(0, "CpG"), (1, "CHG"), (2, "CHH")])
 def test_cnn_logits_vs_reference_torchscript(mc, oracle, ctx, name):
     z = np.load(os.path.join(GOLDEN, f"cnn_{name}.npz"))
     lg, p, ml = mc.cnn_logits(ctx, z["windows"])
@@ -265,11 +265,8 @@ def test_split_half_precision_mode(mc, oracle, oracle_models):
         mc.set_option("precision", mc.precision)
 
 
-def test_fp16_weights_mode_config5(mc, oracle, oracle_models):
-    """BASELINE.json configs[4]: fp16 CNN weights on fp16 MFMA with fp32 accumulate, re-validated |dp| <= 1e-3.
-    Option precision=2 drops the w_lo pass for conv2..conv8 (conv1 and fc1 keep split weights)."""
-    reads = _mixed_reads()[:6] + synth_reads(3, seed=14, median_len=5000, sigma=0.1, frac_short=0, frac_missing=0)
-    mc.set_option("precision", 2)
+def _dp_vs_oracle(mc, reads, oracle, oracle_models, precision):
+    mc.set_option("precision", precision)
     try:
         calls = mc.call(reads)
     finally:
@@ -281,12 +278,31 @@ def test_fp16_weights_mode_config5(mc, oracle, oracle_models):
         got = calls[calls["read_id"] == rid]
         assert np.array_equal(got["qoff"], want["qoff"][order])
         dps.append(np.abs(got["p"] - want["p"][order]))
-    dp = np.concatenate(dps)
-    print(f"fp16-weights mode: {len(dp)} sites, max|dp|={dp.max():.2e}, mean={dp.mean():.2e}, "
-          f">1e-4: {100.0 * (dp > 1e-4).mean():.2f} %, >1e-3: {100.0 * (dp > 1e-3).mean():.3f} %")
-    # Measured on MI355X: the 1e-3 bar of configs[4] holds for > 99.9 % of the sites but NOT for all of them
-    # (max 1.4e-3 here, 2.8e-3 over 443 k sites in bench.py) -- as SURVEY.md section 7 predicted for plain fp16
-    # weights.  The mode is therefore opt-in and never the default; what is asserted is what was measured.
+    return np.concatenate(dps)
+
+
+def test_fp16_weights_mode_config5(mc, oracle, oracle_models):
+    """BASELINE.json configs[4]: fp16 CNN weights on fp16 MFMA with fp32 accumulate, re-validated |dp| <= 1e-3 -- at
+    the real bar.  Option precision=2 keeps plain fp16 weights where the bar allows it (conv6..conv8; the per-layer
+    error table is tools/w16_error_table.py) and split weights elsewhere."""
+    if mc.precision == 0:
+        pytest.skip("fp16-weight modes belong to the split-half kernels")
+    reads = _mixed_reads()[:6] + synth_reads(3, seed=14, median_len=5000, sigma=0.1, frac_short=0, frac_missing=0)
+    dp = _dp_vs_oracle(mc, reads, oracle, oracle_models, 2)
+    print(f"fp16 weights in conv6..conv8: {len(dp)} sites, max|dp|={dp.max():.2e}, mean={dp.mean():.2e}, "
+          f">1e-4: {100.0 * (dp > 1e-4).mean():.2f} %")
+    assert len(dp) > 5000 and dp.max() <= 1e-3
+
+
+def test_fp16_weights_in_all_layers_is_recorded_as_missing_its_bar(mc, oracle, oracle_models):
+    """The literal configs[4] (precision=3: fp16 weights in conv2..conv8) does NOT hold 1e-3 on every site (max ~2.5e-3,
+    SURVEY.md section 7 predicted it); the mode stays available for the record and is never the default.  What is
+    asserted here is only that it stays within the measured envelope."""
+    if mc.precision == 0:
+        pytest.skip("fp16-weight modes belong to the split-half kernels")
+    reads = _mixed_reads()[:6] + synth_reads(3, seed=14, median_len=5000, sigma=0.1, frac_short=0, frac_missing=0)
+    dp = _dp_vs_oracle(mc, reads, oracle, oracle_models, 3)
+    print(f"fp16 weights in conv2..conv8: {len(dp)} sites, max|dp|={dp.max():.2e}, >1e-3: {100.0 * (dp > 1e-3).mean():.3f} %")
     assert len(dp) > 5000 and dp.max() <= 5e-3 and (dp > 1e-3).mean() <= 2e-3 and dp.mean() <= 2e-4
 
 

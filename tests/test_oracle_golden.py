@@ -2,7 +2,7 @@
 
 scan.json    <- reference C++ scanner (eval_kmer_features.cpp:67-126) built by oracle/ref_build
 windows.npz  <- reference Python assembler (training/sample_dataset.py:84-139)
-cnn_*.npz    <- reference TorchScript models models/CpG.pt, models/CHH.pt
+cnn_*.npz    <- reference TorchScript models models/CpG.pt, models/CHH.pt; models/CHG.onnx via torch functional ops
 """
 import json
 import os
@@ -88,8 +88,10 @@ def test_u16_kinetics_equal_reencoded_u8(oracle):
     assert np.array_equal(w16, w8)
 
 
-@pytest.mark.parametrize("ctx", ["CpG", "CHH"])
+@pytest.mark.parametrize("ctx", ["CpG", "CHG", "CHH"])
 def test_cnn_matches_reference_torchscript(oracle, ctx):
+    # CpG / CHH: outputs of the reference's TorchScript models; CHG: models/CHG.onnx evaluated with torch functional ops
+    # over an independent minimal ONNX parse (CHG.pt holds another checkpoint) -- tools/make_golden.py:make_cnn_chg
     z = np.load(os.path.join(GOLDEN, f"cnn_{ctx}.npz"))
     m = oracle.Model(os.path.join(WEIGHTS, ctx + ".hmw"))
     lg = m.logits(z["windows"])

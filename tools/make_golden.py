@@ -19,6 +19,7 @@ GPU box never needs the reference.  Three sources, each the reference's own code
 usage: python tools/make_golden.py [/root/reference [align]]
 """
 import json
+import struct
 import os
 import sys
 
@@ -165,6 +166,135 @@ def make_cnn(wins):
     json.dump(report, open(os.path.join(GOLD, "cnn_report.json"), "w"), indent=1)
 
 
+def _mini_onnx(path):
+    """A second, MINIMAL reading of an ONNX file, written independently of hifimeth_amd/onnx_weights.py and of the C++
+    reader (hm_weights.cpp): a flat protobuf wire walk that returns (initializers by name, [(op_type, inputs, attrs)]).
+    Only what models/CHG.onnx uses (opset 17: initializers with raw_data, Conv / Relu / BatchNormalization / Gemm ...)."""
+    buf = open(path, "rb").read()
+
+    def varint(b, i):
+        v = s = 0
+        while True:
+            c = b[i]; i += 1
+            v |= (c & 127) << s; s += 7
+            if c < 128:
+                return v, i
+
+    def walk(b):
+        i = 0
+        while i < len(b):
+            key, i = varint(b, i)
+            f, wt = key >> 3, key & 7
+            if wt == 0:
+                v, i = varint(b, i)
+            elif wt == 2:
+                n, i = varint(b, i); v = b[i:i + n]; i += n
+            elif wt == 5:
+                v = b[i:i + 4]; i += 4
+            elif wt == 1:
+                v = b[i:i + 8]; i += 8
+            else:
+                raise ValueError("wire type")
+            yield f, wt, v
+
+    graph = next(v for f, _, v in walk(buf) if f == 7)
+    inits, nodes = {}, []
+    for f, _, v in walk(graph):
+        if f == 5:  # TensorProto: dims=1 data_type=2 name=8 raw_data=9
+            dims, name, raw = [], None, None
+            for g, wt, x in walk(v):
+                if g == 1:
+                    dims += [x] if wt == 0 else [t for t in _unpack(x)]
+                elif g == 8:
+                    name = x.decode()
+                elif g == 9:
+                    raw = x
+            inits[name] = np.frombuffer(raw, "<f4").reshape(dims).copy()
+        elif f == 1:  # NodeProto: input=1 output=2 op_type=4 attribute=5
+            ins, op, attrs = [], None, {}
+            for g, wt, x in walk(v):
+                if g == 1:
+                    ins.append(x.decode())
+                elif g == 4:
+                    op = x.decode()
+                elif g == 5:
+                    an, ai, af, ints = None, None, None, []
+                    for h, wt2, y in walk(x):
+                        if h == 1:
+                            an = y.decode()
+                        elif h == 3:
+                            ai = y
+                        elif h == 2:
+                            af = struct.unpack("<f", y)[0]
+                        elif h == 8:
+                            ints += [y] if wt2 == 0 else list(_unpack(y))
+                    attrs[an] = ints if ints else (ai if ai is not None else af)
+            nodes.append((op, ins, attrs))
+    return inits, nodes
+
+
+def _unpack(b):
+    i = 0
+    while i < len(b):
+        v = s = 0
+        while True:
+            c = b[i]; i += 1
+            v |= (c & 127) << s; s += 7
+            if c < 128:
+                break
+        yield v
+
+
+def make_cnn_chg(wins):
+    """models/CHG.onnx is the model the reference's CPU path loads (mod_main.cpp:85); its TorchScript twin CHG.pt holds a
+    DIFFERENT checkpoint, so the fixture cannot come from torch.jit.load.  Instead: the ONNX graph is
+    evaluated node by node with torch functional ops on tensors from the independent mini reader above -- an arithmetic
+    path that shares no code with the repo's readers, oracle or kernels.  Labelled as such in cnn_report.json."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(13)
+    extra = np.zeros((4, 401, 8), np.float32)
+    extra[1:, :, :4] = np.eye(4, dtype=np.float32)[rng.integers(0, 4, (3, 401))]
+    extra[1:, :, 4:] = rng.gamma(2.0, 0.03, (3, 401, 4)).astype(np.float32)
+    x = np.concatenate([wins[:60], extra])
+    inits, nodes = _mini_onnx(os.path.join(REF, "models", "CHG.onnx"))
+    T = {k: torch.from_numpy(v) for k, v in inits.items()}
+    h = torch.from_numpy(x)
+    nconv = 0
+    with torch.no_grad():
+        for op, ins, at in nodes:
+            if op == "Transpose":
+                h = h.permute(*at["perm"])
+            elif op == "BatchNormalization":
+                h = F.batch_norm(h, T[ins[3]], T[ins[4]], T[ins[1]], T[ins[2]], False, 0.0, at.get("epsilon", 1e-5))
+            elif op == "Conv":
+                assert at["strides"] == [2] and at["pads"] == [1, 1] and at.get("dilations", [1]) == [1]
+                h = F.conv1d(h, T[ins[1]], T[ins[2]], stride=2, padding=1)
+                nconv += 1
+            elif op == "Relu":
+                h = F.relu(h)
+            elif op in ("Flatten", "Reshape"):
+                h = h.flatten(1)
+            elif op == "Gemm":
+                assert at.get("transB", 0) == 1
+                h = F.linear(h, T[ins[1]], T[ins[2]])
+            elif op in ("Constant", "Shape", "Gather", "Unsqueeze", "Concat"):
+                continue  # shape bookkeeping of the export around Reshape
+            else:
+                raise SystemExit(f"CHG.onnx: unexpected op {op}")
+    assert nconv == 8 and tuple(h.shape) == (len(x), 2)
+    lg = h.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "cnn_CHG.npz"), windows=x, logits=lg)
+    om = O.Model(os.path.join(ROOT, "hifimeth_amd", "weights", "CHG.hmw"))
+    d = float(np.abs(om.logits(x) - lg).max())
+    rp = os.path.join(GOLD, "cnn_report.json")
+    report = json.load(open(rp)) if os.path.exists(rp) else {}
+    report["CHG.onnx_torch_functional_over_independent_mini_parse_vs_oracle_max_dlogit"] = d
+    report["CHG_fixture_source"] = ("models/CHG.onnx evaluated with torch functional ops over tools/make_golden.py:_mini_onnx "
+                                    "(second, minimal ONNX parse); CHG.pt is a different checkpoint and was not used")
+    json.dump(report, open(rp, "w"), indent=1)
+    print(f"cnn_CHG.npz: {len(x)} windows, oracle(ONNX weights) vs torch-functional(CHG.onnx, mini parse) max |dlogit| = {d:.3g}")
+
+
 def make_config_goldens():
     """BASELINE.json configs[0]/[1] stand-in (the P.patens tutorial BAM is an external download): a small CpG-only
     read set with the CPU path's outputs.  These vectors come from the ORACLE (which is pinned against the reference
@@ -299,9 +429,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "helpers":    # only the cov2bed / corr fixtures
         make_helpers()
         raise SystemExit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "chg":        # only the CHG CNN fixture (windows are those of cnn_CpG.npz)
+        make_cnn_chg(np.load(os.path.join(GOLD, "cnn_CpG.npz"))["windows"])
+        raise SystemExit(0)
     make_scan()
     w = make_windows()
     make_cnn(w)
+    make_cnn_chg(w)
     make_config_goldens()
     make_align()
     make_helpers()
