@@ -20,6 +20,11 @@ class hm_call_t(C.Structure):
                 ("scaled_prob", C.c_uint8), ("reserved", C.c_uint8), ("p", C.c_float)]
 
 
+class hm_read_t(C.Structure):
+    _fields_ = [("read_id", C.c_int32), ("l_qseq", C.c_int32), ("flag", C.c_int32), ("width", C.c_uint8 * 4),
+                ("seq4", C.c_void_p), ("kin", C.c_void_p * 4)]
+
+
 class hm_timing_t(C.Structure):
     _fields_ = [("prep_ms", C.c_double), ("scan_ms", C.c_double), ("emit_ms", C.c_double), ("window_ms", C.c_double),
                 ("front_ms", C.c_double * 3), ("tail_ms", C.c_double * 3),
@@ -76,6 +81,7 @@ def lib():
         "hm_drain": (i64, [vp, vp, i64]),
         "hm_batch_begin": (vp, [vp]),
         "hm_batch_submit_read": (C.c_int, [vp, i32, i32, i32, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int]),
+        "hm_batch_submit_reads": (i64, [vp, vp, i64, C.c_int, vp]),
         "hm_batch_staged_bases": (i64, [vp]),
         "hm_batch_enqueue": (C.c_int, [vp]),
         "hm_batch_done": (C.c_int, [vp]),

@@ -21,6 +21,11 @@ CPG, CHG, CHH = 0, 1, 2
 CTX_NAMES = ("CpG", "CHG", "CHH")
 KMER, FEATS = 401, 8
 
+# hm_read_t as a numpy record (pointers as integers): descriptors of a whole slab for Batch.submit_block
+READ_DTYPE = np.dtype([("read_id", "<i4"), ("l_qseq", "<i4"), ("flag", "<i4"), ("width", "u1", 4), ("seq4", "<u8"),
+                       ("kin", "<u8", 4)], align=True)
+assert READ_DTYPE.itemsize == C.sizeof(_lib.hm_read_t)
+
 CALL_DTYPE = np.dtype([("read_id", "<i4"), ("qoff", "<i4"), ("strand", "u1"), ("ctx", "u1"),
                        ("scaled_prob", "u1"), ("reserved", "u1"), ("p", "<f4")])
 assert CALL_DTYPE.itemsize == C.sizeof(_lib.hm_call_t) == 16
@@ -169,7 +174,10 @@ class MethylationCaller:
 
         for slab in slabs:
             b = self.begin_batch()
-            b.submit_all(slab)
+            if isinstance(slab, ReadBlock):
+                b.submit_block(slab, self.stage_threads)
+            else:
+                b.submit_all(slab)
             b.enqueue()
             inflight.append(b)
             while len(inflight) > 1 and (inflight[0].done() or len(inflight) >= self.max_inflight):
@@ -179,6 +187,7 @@ class MethylationCaller:
         return total
 
     max_inflight = 3
+    stage_threads = 4
 
     # -- seams -------------------------------------------------------------------------------------
     def scan_sites(self, ctx: int):
@@ -226,6 +235,34 @@ class MethylationCaller:
         return d
 
 
+class ReadBlock:
+    """Descriptors (hm_read_t) of a list of reads: what a BAM decoder hands to the engine.  Keeps the arrays alive."""
+
+    def __init__(self, reads, first_id: int = 0):
+        self.reads = list(reads)
+        self.desc = np.zeros(len(self.reads), READ_DTYPE)
+        self._keep = []
+        for i, r in enumerate(self.reads):
+            d = self.desc[i]
+            d["read_id"], d["l_qseq"], d["flag"] = first_id + i, r.l_qseq, r.flag
+            seq4 = np.ascontiguousarray(r.seq4, np.uint8)
+            d["seq4"] = seq4.ctypes.data
+            self._keep.append(seq4)
+            for k, nm in enumerate(("fi", "fp", "ri", "rp")):
+                a = getattr(r, nm)
+                if a is None or len(a) != r.l_qseq:   # bam_auxB_len != l_qseq -> init() == false (bam_info.cpp:447)
+                    d["kin"][k], d["width"][k] = 0, 1
+                    continue
+                a = np.ascontiguousarray(a)
+                if a.dtype.itemsize not in (1, 2):
+                    raise ValueError("kinetics arrays must be uint8 (B:C) or uint16 (B:S)")
+                d["kin"][k], d["width"][k] = a.ctypes.data, a.dtype.itemsize
+                self._keep.append(a)
+
+    def __len__(self):
+        return len(self.reads)
+
+
 class Batch:
     """One slot of the engine's pipeline: stage -> enqueue (returns at once) -> wait -> release."""
 
@@ -241,6 +278,12 @@ class Batch:
         for i, r in enumerate(reads):
             n += self.submit(first_id + i, r)
         return n
+
+    def submit_block(self, block: "ReadBlock", threads: int = 4) -> int:
+        """All reads of a prepared ReadBlock in ONE call (hm_batch_submit_reads): the copies into the pinned slab run on
+        `threads` host threads.  Same result as submit() read by read."""
+        rc = self._L.hm_batch_submit_reads(self._h, block.desc.ctypes.data_as(C.c_void_p), len(block.desc), threads, None)
+        return self._mc._check(rc, "hm_batch_submit_reads")
 
     def staged_bases(self) -> int:
         return self._L.hm_batch_staged_bases(self._h)

@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hifimeth_hip.h"
@@ -886,6 +887,92 @@ int hm_batch_submit_read(hm_batch_t* b, int32_t read_id, int32_t l_qseq, int32_t
     if (!b) return HM_EINVAL;
     if (b->state != hm_batch::STAGING) return fail(b->e, HM_ESTATE, "hm_batch_submit_read: batch is not being staged");
     return stage_read(b, read_id, l_qseq, flag, seq4, fi, fi_w, fp, fp_w, ri, ri_w, rp, rp_w);
+}
+
+int64_t hm_batch_submit_reads(hm_batch_t* b, const hm_read_t* reads, int64_t n, int threads, uint8_t* accepted) {
+    if (!b || (!reads && n > 0) || n < 0) return HM_EINVAL;
+    hm_engine* e = b->e;
+    if (b->state != hm_batch::STAGING) return fail(e, HM_ESTATE, "hm_batch_submit_reads: batch is not being staged");
+    // pass 1 (serial): descriptors, chunk / tile lists and every read's place in the slab -- stage_read with the copies left out
+    struct Copy {
+        const void* src;
+        size_t off, bytes;
+    };
+    std::vector<Copy> copies;
+    copies.reserve((size_t)n * 5);
+    int64_t taken = 0;
+    try {
+        HIP_TRY(hipSetDevice(e->device));
+        size_t need_total = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const hm_read_t& r = reads[i];
+            const size_t L = (size_t)std::max(r.l_qseq, 0);
+            need_total += align16((L + 1) / 2) + 4 * align16(L * 2);
+        }
+        if (b->slab.n + need_total > b->slab.cap) b->slab.reserve(std::max<size_t>(b->slab.n + need_total, size_t(64) << 20));
+        for (int64_t i = 0; i < n; ++i) {
+            const hm_read_t& r = reads[i];
+            if (accepted) accepted[i] = 0;
+            if (r.l_qseq < 0) return fail(e, HM_EINVAL, "hm_batch_submit_reads: negative read length");
+            if (r.l_qseq < e->min_read_size || !r.kin[0] || !r.kin[1] || !r.kin[2] || !r.kin[3]) continue;
+            if (!r.seq4) return fail(e, HM_EINVAL, "hm_batch_submit_reads: seq4 is NULL");
+            if (b->total_bases + (int64_t)r.l_qseq + 4 >= (int64_t(1) << 31))
+                return fail(e, HM_ENOMEM, "hm_batch_submit_reads: batch would exceed 2^31 bases; queue it first");
+            for (int k = 0; k < 4; ++k)
+                if (r.width[k] != 1 && r.width[k] != 2) return fail(e, HM_EINVAL, "kinetics element width must be 1 (B:C) or 2 (B:S)");
+            const size_t L = (size_t)r.l_qseq;
+            ReadDesc rd{};
+            auto place = [&](const void* src, size_t bytes) {
+                const int64_t off = (int64_t)b->slab.n;
+                copies.push_back(Copy{src, (size_t)off, bytes});
+                b->slab.n += align16(bytes);
+                return off;
+            };
+            rd.off_seq = place(r.seq4, (L + 1) / 2);
+            rd.off_fi = place(r.kin[0], L * r.width[0]);
+            rd.off_fp = place(r.kin[1], L * r.width[1]);
+            rd.off_ri = place(r.kin[2], L * r.width[2]);
+            rd.off_rp = place(r.kin[3], L * r.width[3]);
+            rd.base_off = b->total_bases;
+            rd.len = r.l_qseq;
+            rd.flag = r.flag;
+            rd.read_id = r.read_id;
+            for (int k = 0; k < 4; ++k) rd.w[k] = r.width[k];
+            const int ridx = (int)b->reads.n;
+            if (b->groups.empty() || b->groups.back().bases >= e->group_bases)
+                b->groups.push_back(hm_batch::Group{(int)b->chunks.n, (int)b->chunks.n, (int)b->tiles.n, (int)b->tiles.n, 0, 0});
+            hm_batch::Group& g = b->groups.back();
+            const int ntile = (r.l_qseq + 2 * TR_PAD + TR_OWN - 1) / TR_OWN;
+            b->rinfo.push_back(RInfo{b->total_bases, r.l_qseq, (int32_t)g.rows});
+            for (int t = 0; t < ntile; ++t) b->tiles.push_back(TrunkTile{ridx, -TR_PAD + t * TR_OWN});
+            b->reads.push_back(rd);
+            for (int st = 0; st < r.l_qseq; st += CHUNK) b->chunks.push_back(Chunk{ridx, st});
+            g.rows += (int64_t)ntile * TR_OWN;
+            g.bases += r.l_qseq;
+            g.chunk_hi = (int)b->chunks.n;
+            g.tile_hi = (int)b->tiles.n;
+            b->total_bases += (int64_t)((L + 3) & ~size_t(3));
+            if (accepted) accepted[i] = 1;
+            ++taken;
+        }
+    } catch (const HipErr& h) {
+        return fail_hip(e, h);
+    }
+    // pass 2: the copies, dealt to the host threads
+    const int nt = (int)std::clamp<int64_t>(threads, 1, 64);
+    uint8_t* base = b->slab.p;
+    auto run = [&](int t) {
+        for (size_t i = (size_t)t; i < copies.size(); i += (size_t)nt) memcpy(base + copies[i].off, copies[i].src, copies[i].bytes);
+    };
+    if (nt == 1 || copies.size() < 64) {
+        for (int t = 0; t < nt; ++t) run(t);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(run, t);
+        run(0);
+        for (auto& th : pool) th.join();
+    }
+    return taken;
 }
 
 int64_t hm_batch_staged_bases(const hm_batch_t* b) { return b ? b->total_bases : HM_EINVAL; }

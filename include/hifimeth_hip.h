@@ -126,6 +126,16 @@ hm_batch_t* hm_batch_begin(hm_engine_t* e);
 int hm_batch_submit_read(hm_batch_t* b, int32_t read_id, int32_t l_qseq, int32_t flag, const uint8_t* seq4,
                          const void* fi, int fi_width, const void* fp, int fp_width, const void* ri, int ri_width,
                          const void* rp, int rp_width);
+/* Bulk form: n reads in one call, copied into the slab by `threads` host threads (the per-read layout is fixed by a
+ * serial pass first, so the result is identical to n hm_batch_submit_read calls in order).  A read that would be passed
+ * through uncalled is skipped exactly as there; accepted[i] (may be NULL) tells which.  Returns the number accepted. */
+typedef struct {
+    int32_t read_id, l_qseq, flag;
+    uint8_t width[4];     /* element width of fi, fp, ri, rp: 1 (B:C) or 2 (B:S) */
+    const uint8_t* seq4;
+    const void* kin[4];   /* fi, fp, ri, rp; NULL = tag missing */
+} hm_read_t;
+int64_t hm_batch_submit_reads(hm_batch_t* b, const hm_read_t* reads, int64_t n, int threads, uint8_t* accepted);
 int64_t hm_batch_staged_bases(const hm_batch_t* b);
 /* Queues the batch: async H2D on the slot's stream, scanner + CNN + result packing on the engine's compute stream (site
  * counts are consumed on the device), async D2H of the totals.  Returns at once; batches compute in queueing order. */

@@ -456,6 +456,23 @@ def test_batch_pipeline_matches_synchronous_calls(mc):
         assert ns[3] == len(w) and sum(ns[:3]) == ns[3] and [int((w["ctx"] == c).sum()) for c in range(3)] == ns[:3]
 
 
+def test_bulk_submit_matches_read_by_read(mc):
+    """hm_batch_submit_reads (one call per slab, copies on several host threads) stages exactly what hm_batch_submit_read
+    stages read by read: same calls, byte for byte, including skipped reads (short / missing tag / B:S arrays)."""
+    from hifimeth_amd.caller import ReadBlock
+    reads = _mixed_reads() + synth_reads(12, seed=71, median_len=2200, sigma=0.5, frac_wide=0.3, frac_short=0.2, frac_missing=0.2)
+    want = mc.call(reads).copy()
+    blk = ReadBlock(reads)
+    for threads in (1, 5):
+        b = mc.begin_batch()
+        n = b.submit_block(blk, threads)
+        assert n == sum(1 for r in reads if r.has_kinetics() and r.l_qseq >= 1000)
+        b.enqueue()
+        got = b.wait().copy()
+        b.release()
+        assert got.tobytes() == want.tobytes()
+
+
 def test_batches_staged_from_several_threads(mc):
     """Different batches may be staged by different host threads (the reference's workers pull from a shared queue,
     sam_batch.hpp:38-54); an empty batch and a batch of skipped reads go through the pipeline too."""
