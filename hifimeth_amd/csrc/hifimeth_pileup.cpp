@@ -26,6 +26,25 @@
 
 using namespace hmbam;
 
+// CIGAR of a record as uint32 ops.  A CIGAR of more than 65535 operations does not fit the 16-bit n_cigar_op field: the
+// record then carries the placeholder <l_seq>S<ref_len>N and the real operations in a CG:B,I tag (SAMv1 section 4.2.2);
+// htslib's sam_read1 -- what the reference's pileup reads with -- swaps them back in, and so does this.
+static void real_cigar(const BamRecord& r, std::vector<uint32_t>& cig) {
+    cig.resize((size_t)r.n_cigar());
+    if (!cig.empty()) memcpy(cig.data(), r.cigar_bytes(), 4 * cig.size());
+    if (cig.size() != 2 || (cig[0] & 15) != 4 || (int32_t)(cig[0] >> 4) != r.l_qseq() || (cig[1] & 15) != 3) return;
+    const uint8_t* p = r.data.data() + r.aux_offset();
+    const uint8_t* end = r.data.data() + r.data.size();
+    AuxField f;
+    while (p < end && next_aux(p, end, f))
+        if (f.tag[0] == 'C' && f.tag[1] == 'G' && f.type == 'B' && (f.subtype == 'I' || f.subtype == 'i')) {
+            cig.resize(f.count);
+            memcpy(cig.data(), f.payload, 4 * (size_t)f.count);
+            return;
+        }
+}
+
+
 namespace {
 void report_thresholds(const uint64_t* bins, uint8_t thr[3]);
 }  // namespace
@@ -517,10 +536,9 @@ int cmd_eval(int argc, char** argv) {
                 hm_pileup_destroy(pe);
                 return EXIT_FAILURE;
             }
-            cig.resize((size_t)r.n_cigar());
-            if (!cig.empty()) memcpy(cig.data(), r.cigar_bytes(), 4 * cig.size());
+            real_cigar(r, cig);
             if (hm_pileup_submit_read(pe, (uint32_t)order, r.flag(), tid2sid[(size_t)tid], r.pos(), r.mapq(), r.l_qseq(), r.seq4(),
-                                      r.n_cigar(), cig.data(), (int64_t)mods[(size_t)k].size(), mods[(size_t)k].data()) < 0)
+                                      (int32_t)cig.size(), cig.data(), (int64_t)mods[(size_t)k].size(), mods[(size_t)k].data()) < 0)
                 return die(std::string("read ") + reinterpret_cast<const char*>(r.data.data() + 32));
         }
         if (hm_pileup_run(pe) != HM_OK) return die("projection");
@@ -745,10 +763,9 @@ int cmd_pileup(int argc, char** argv) {
                 fprintf(stderr, "ERROR: Sequence name %s does not exist\n", hdr.refs[(size_t)tid].first.c_str());
                 return fail_out();
             }
-            cig.resize((size_t)r.n_cigar());
-            if (!cig.empty()) memcpy(cig.data(), r.cigar_bytes(), 4 * cig.size());
+            real_cigar(r, cig);
             const int rc = hm_pileup_submit_read(pe, (uint32_t)order, r.flag(), tid2sid[(size_t)tid], r.pos(), r.mapq(), r.l_qseq(),
-                                                 r.seq4(), r.n_cigar(), cig.data(), (int64_t)b.mods[(size_t)k].size(),
+                                                 r.seq4(), (int32_t)cig.size(), cig.data(), (int64_t)b.mods[(size_t)k].size(),
                                                  b.mods[(size_t)k].data());
             if (rc < 0) {
                 fprintf(stderr, "ERROR: read %s: %s\n", reinterpret_cast<const char*>(r.data.data() + 32), hm_pileup_last_error(pe));

@@ -152,7 +152,13 @@ struct hm_engine {
     // misses its bar, kept for the record)
     int precision = 1;
     int max_slots = 3;  // batch slots of the asynchronous API (the legacy calls use one more, slot 0)
-    int trunk = 1;      // 1 = conv1..conv4 once per read position (hm_trunk.hip), 0 = once per site (front kernels)
+    // conv1..conv4: 1 = once per read position (dense trunk, hm_trunk.hip), 0 = once per site (front kernels), 2 = per
+    // context whichever is cheaper at the site density of the previous batch: the trunk costs ~0.9 ns per base and strand
+    // view whatever the number of sites, the per-site kernels ~55 ns per site more than the trunk path's per-site share,
+    // so the trunk wins above ~1.7 % sites per base (CHH, two views: 3.3 %) -- everything but CpG-only runs on
+    // CpG-poor genomes.  Both paths give the same calls to within fp32 re-association.
+    int trunk = 2;
+    double density[3] = {-1, -1, -1};  // sites per base of the last finished batch (-1: none yet -> trunk)
     int64_t group_bases = int64_t(2) << 20;  // reads per trunk group: their maps take ~3.9 KB per base
     bool stamps_on = false;
     std::vector<unsigned long long> stamp_sum;
@@ -496,7 +502,7 @@ void enqueue_upload(hm_batch* b) {
 // Dense trunk path: per read group and context  trunk (conv1..conv4 once per view position) -> edge (the two conv4 rows
 // per site that are not samples of the maps) -> tail (gathers its conv4 rows).  Every launch is sized by host-known
 // quantities (tiles) or reads its site range from the scanned chunk counters on the device.
-void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans) {
+void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
     hm_engine* e = b->e;
     int64_t max_rows = 1, max_bases = 1;
     for (const auto& g : b->groups) {
@@ -518,7 +524,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans) {
                              e->d_e4.as<uint16_t>(), g.rows, e->d_zeros.as<uint16_t>()};
         const int n_tiles = g.tile_hi - g.tile_lo;
         for (int c = 0; c < 3; ++c) {
-            if (!(e->ctx_mask >> c & 1)) continue;
+            if (!(ctx_mask >> c & 1)) continue;
             const DeviceModel& dm = e->model[c];
             const int n_views = c == CHH ? 2 : 1;  // CpG / CHG are called on the forward strand only (eval_kmer_features.cpp:89-126)
             {
@@ -570,9 +576,14 @@ void enqueue_run(hm_batch* b) {
                     b->d_csites.as<Site>(), b->d_opos.as<int32_t>());
         sp.end();
     }
-    if (e->trunk && e->precision >= 1) {
-        run_trunk_path(b, spans);
-    } else {
+    int trunk_mask = 0;  // contexts whose conv1..conv4 run as the dense trunk
+    if (e->precision >= 1 && e->trunk)
+        for (int c = 0; c < 3; ++c) {
+            const double thr = c == CHH ? 0.033 : 0.017;
+            if ((e->ctx_mask >> c & 1) && (e->trunk == 1 || e->density[c] < 0 || e->density[c] >= thr)) trunk_mask |= 1 << c;
+        }
+    if (trunk_mask) run_trunk_path(b, spans, trunk_mask);
+    if ((e->ctx_mask & ~trunk_mask) != 0) {
     // The CNN launches cover [0, bound) of every context's list in windows of `sb` sites; how many sites a window
     // really holds is resolved on the device.  bound = staged bases (a position carries at most one site); the
     // window grows with the batch so that a batch never needs more than ~48 launch pairs per context.
@@ -581,7 +592,7 @@ void enqueue_run(hm_batch* b) {
     sb = std::min<int64_t>(sb, int64_t(1) << 20);
     e->d_act4.reserve((size_t)std::min<int64_t>(std::max<int64_t>(bound, 1), sb) * ACT4_FLOATS * sizeof(float));
     for (int c = 0; c < 3; ++c) {
-        if (!(e->ctx_mask >> c & 1)) continue;
+        if (!(e->ctx_mask >> c & 1) || (trunk_mask >> c & 1)) continue;
         for (int64_t off = 0; off < bound; off += sb) {
             const SiteRange sr{b->d_csites.as<Site>(), b->d_totals.as<int32_t>(), c, (int32_t)off,
                                (int32_t)std::min<int64_t>(sb, bound - off)};
@@ -616,6 +627,10 @@ int wait_totals(hm_batch* b) {
         HIP_TRY(hipEventSynchronize(b->ev_out));
         memcpy(b->totals, b->h_totals, sizeof b->totals);
         b->have_totals = true;
+        if (b->total_bases > 0) {
+            std::lock_guard<std::mutex> lk(e->mu);
+            for (int c = 0; c < 3; ++c) e->density[c] = (double)b->totals[c] / (double)b->total_bases;
+        }
         collect_timing(e, b->spans, b->totals);
     }
     if (*b->h_err) {
@@ -735,7 +750,9 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
         if (value < TAIL_SITES) return fail(e, HM_EINVAL, "sub_batch_sites too small");
         e->sub_batch = value / TAIL_SITES * TAIL_SITES;
     } else if (k == "trunk") {
-        e->trunk = value != 0;
+        if (value < 0 || value > 2) return fail(e, HM_EINVAL, "trunk must be 0 (per site), 1 (dense trunk) or 2 (by site density)");
+        e->trunk = (int)value;
+        for (double& d : e->density) d = -1;
     } else if (k == "group_bases") {
         if (value < 1) return fail(e, HM_EINVAL, "group_bases must be positive");
         e->group_bases = value;

@@ -563,7 +563,9 @@ int hm_pileup_submit_read(hm_pileup_t* p, uint32_t order, int32_t flag, int32_t 
     if (n_mods <= 0 || (flag & 4)) return 0;  // pileup.cpp:233-235
     if (n_mods >= (int64_t(1) << 22)) return pfail(p, HM_EINVAL, "more than 2^22 modification entries in one read");
     if (l_qseq < 0 || !seq4 || n_cigar < 0 || (n_cigar && !cigar) || !mods) return pfail(p, HM_EINVAL, "hm_pileup_submit_read: bad argument");
-    if (order >= (1u << 30)) return pfail(p, HM_EINVAL, "record order must be < 2^30");
+    // key = order << 2 | motif must stay below 2^31: the multi-GPU path max-reduces the key plane as int32
+    // (hifimeth_amd/pileup.py: reduce_scatter_planes), where a set top bit would lose against an empty locus
+    if (order >= (1u << 29)) return pfail(p, HM_EINVAL, "record order must be < 2^29");
     if (l_qseq >= (1 << 22)) return pfail(p, HM_EINVAL, "reads of 2^22 bases or more are not supported");
     const int n_seqs = (int)p->seq_off.size() - 1;
     if (sid < 0 || sid >= n_seqs) return pfail(p, HM_EINVAL, "sequence index out of range");

@@ -212,7 +212,8 @@ def allreduce_histograms(dist, bins: np.ndarray, device: str = "cpu") -> np.ndar
 
 def reduce_scatter_planes(dist, pcov, ncov, key, force: bool = False):
     """-> (pcov, ncov, key, base): this rank's slice of the job-wide planes, `base` = its first locus.
-    pcov / ncov are summed, key (order << 2 | motif, < 2^31 so int32 compares like uint32) takes the maximum.
+    pcov / ncov are summed, key (order << 2 | motif; hm_pileup_submit_read keeps order < 2^29, so the key is < 2^31 and
+    compares as int32 exactly like the device's uint32 atomicMax) takes the maximum.
     Planes must be padded to world * chunk elements.  RCCL reduce-scatters; gloo (CPU tests) all-reduces and slices."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0

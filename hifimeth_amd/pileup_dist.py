@@ -32,6 +32,11 @@ def run(reference: str, bam: str, prefix: str, min_mapq: int = 0, min_pi: float 
     dist = D.init_process_group(backend, force=bool(os.environ.get("HM_FORCE_COLLECTIVES")))
     on_gpu = dist is None or dist.get_backend() == "nccl"
     text, refs, records = read_bam(bam)
+    def leave(code):
+        if dist is not None:
+            dist.destroy_process_group()
+        return code
+
     if not refs or not is_coordinate_sorted(text):          # s_bam_is_mapped_and_sorted (pileup.cpp:438-459)
         if rank == 0:
             print("ERROR: Methylation frequency could not be computed due to the following errors:", file=log)
@@ -39,9 +44,17 @@ def run(reference: str, bam: str, prefix: str, min_mapq: int = 0, min_pi: float 
                 print("BAM is not mapped", file=log)
             if not is_coordinate_sorted(text):
                 print("BAM is not sorted", file=log)
-        return 1
+        return leave(1)                                      # every rank sees the same header: all leave together
     genome = load_fasta(reference)
     sid_of = {n: i for i, (n, _) in enumerate(genome)}
+    # a reference name the FASTA lacks is a property of the header, known to every rank before any collective: checked
+    # here, by all, so that no rank is left waiting in the histogram all-reduce for one that has already exited
+    used = {rec.tid for rec in records if not rec.flag & 4 and rec.mm is not None}
+    missing = sorted(refs[t][0] for t in used if refs[t][0] not in sid_of)
+    if missing:
+        if rank == 0:
+            print(f"ERROR: Sequence name {missing[0]} does not exist", file=log)
+        return leave(1)
     n_loci = sum(len(s) for _, s in genome)
     ranges = locus_ranges(n_loci, world)
     chunk = max(1, (n_loci + world - 1) // world)
@@ -55,10 +68,7 @@ def run(reference: str, bam: str, prefix: str, min_mapq: int = 0, min_pi: float 
     for order, rec in enumerate(records):
         if (order // slab) % world != rank or rec.flag & 4 or rec.mm is None:
             continue
-        name = refs[rec.tid][0]
-        if name not in sid_of:
-            raise SystemExit(f"ERROR: Sequence name {name} does not exist")
-        rec.tid = sid_of[name]
+        rec.tid = sid_of[refs[rec.tid][0]]
         staged += pu.add(rec, order=order)
         if staged >= batch:
             pu.flush()

@@ -214,7 +214,7 @@ int hm_pileup_set_reference(hm_pileup_t* p, int32_t n_seqs, const int64_t* seq_l
  * e.g. torch tensors that a RCCL reduce-scatter will consume.  The caller zeroes them. */
 int hm_pileup_use_planes(hm_pileup_t* p, void* pcov, void* ncov, void* key);
 int hm_pileup_planes(hm_pileup_t* p, void** pcov, void** ncov, void** key, int64_t* n_loci);
-/* One mapped record: `order` = its index in the BAM (decides the motif of a locus hit by two classes), `sid` =
+/* One mapped record: `order` = its index in the BAM, < 2^29 (decides the motif of a locus hit by two classes), `sid` =
  * index into the reference sequences, SEQ 4-bit packed and CIGAR as the BAM record stores them, `mods` = its
  * parsed MM/ML lists.  Returns 1 if staged, 0 if the record contributes nothing (unmapped, no mods), < 0 on
  * error (illegal base nibble, alignment running past the read or the reference sequence). */

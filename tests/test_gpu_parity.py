@@ -456,6 +456,24 @@ def test_batch_pipeline_matches_synchronous_calls(mc):
         assert ns[3] == len(w) and sum(ns[:3]) == ns[3] and [int((w["ctx"] == c).sum()) for c in range(3)] == ns[:3]
 
 
+def test_path_follows_site_density(oracle, oracle_models):
+    """Option trunk=2 (default): per context, conv1..conv4 run as the dense trunk or per site, whichever is cheaper at the
+    site density of the previous batch.  A CpG-only run on a CpG-poor genome (0.3 % sites per base) switches to the
+    per-site kernels after its first batch; both batches hold the 1e-4 bar and agree with each other to ~1e-5."""
+    from hifimeth_amd import MethylationCaller
+    reads = synth_reads(6, seed=123, gc=0.11, median_len=5000, sigma=0.2, frac_short=0, frac_missing=0, frac_wide=0)
+    with MethylationCaller(contexts="cpg", timing=True) as m:
+        a = m.call(reads).copy()
+        t1 = m.timing(reset=True)
+        b = m.call(reads).copy()
+        t2 = m.timing()
+    assert sum(t1["trunk_launches"]) > 0 and sum(t1["front_launches"]) == 0      # first batch: density unknown -> trunk
+    assert sum(t2["trunk_launches"]) == 0 and sum(t2["front_launches"]) > 0      # then: 0.3 % < 1.7 % -> per site
+    assert len(a) == len(b) > 20 and np.array_equal(a["qoff"], b["qoff"]) and np.abs(a["p"] - b["p"]).max() < 2e-5
+    n, nml, worst = _check_calls(b, reads, oracle, oracle_models, 1)
+    assert n == len(b) and worst <= DP_TOL
+
+
 def test_bulk_submit_matches_read_by_read(mc):
     """hm_batch_submit_reads (one call per slab, copies on several host threads) stages exactly what hm_batch_submit_read
     stages read by read: same calls, byte for byte, including skipped reads (short / missing tag / B:S arrays)."""
