@@ -47,14 +47,7 @@ def run(reference: str, bam: str, prefix: str, min_mapq: int = 0, min_pi: float 
         return leave(1)                                      # every rank sees the same header: all leave together
     genome = load_fasta(reference)
     sid_of = {n: i for i, (n, _) in enumerate(genome)}
-    # a reference name the FASTA lacks is a property of the header, known to every rank before any collective: checked
-    # here, by all, so that no rank is left waiting in the histogram all-reduce for one that has already exited
-    used = {rec.tid for rec in records if not rec.flag & 4 and rec.mm is not None}
-    missing = sorted(refs[t][0] for t in used if refs[t][0] not in sid_of)
-    if missing:
-        if rank == 0:
-            print(f"ERROR: Sequence name {missing[0]} does not exist", file=log)
-        return leave(1)
+    missing = None
     n_loci = sum(len(s) for _, s in genome)
     ranges = locus_ranges(n_loci, world)
     chunk = max(1, (n_loci + world - 1) // world)
@@ -68,12 +61,25 @@ def run(reference: str, bam: str, prefix: str, min_mapq: int = 0, min_pi: float 
     for order, rec in enumerate(records):
         if (order // slab) % world != rank or rec.flag & 4 or rec.mm is None:
             continue
-        rec.tid = sid_of[refs[rec.tid][0]]
+        name = refs[rec.tid][0]
+        if name not in sid_of:                               # only the rank that owns the record sees it: flag, do not exit
+            missing = name
+            break
+        rec.tid = sid_of[name]
         staged += pu.add(rec, order=order)
         if staged >= batch:
             pu.flush()
             staged = 0
     pu.flush()
+    # a failed rank must not leave the others waiting in the collectives below: agree on the error first
+    bad = torch.tensor([1 if missing else 0], dtype=torch.int32, device=dev if on_gpu else "cpu")
+    if dist is not None:
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+    if int(bad.item()):
+        if missing:
+            print(f"ERROR: Sequence name {missing} does not exist", file=log)
+        pu.close()
+        return leave(1)
     bins = allreduce_histograms(dist, pu.histograms(), device=str(dev) if on_gpu else "cpu") if dist is not None \
         else pu.histograms()
     thr = []
