@@ -296,7 +296,6 @@ def main():
         gpu_ms["front_ms"] = front_ms
         gpu_ms["trunk_ms"] = trunk_ms
         gpu_ms["edge_ms"] = sum(tm["edge_ms"])
-        gpu_ms["conv5_ms"] = sum(tm["conv5_ms"])
         gpu_ms["tail_ms"] = sum(tm["tail_ms"])
         gpu_ms["empty_launches"] = tm["empty_launches"]
         out = {

@@ -35,8 +35,7 @@ class hm_timing_t(C.Structure):
                 ("pack_launches", C.c_int64), ("empty_launches", C.c_int64),
                 ("trunk_ms", C.c_double * 3), ("edge_ms", C.c_double * 3),
                 ("trunk_launches", C.c_int64 * 3), ("edge_launches", C.c_int64 * 3),
-                ("trunk_positions", C.c_int64 * 3),
-                ("conv5_ms", C.c_double * 3), ("conv5_launches", C.c_int64 * 3)]
+                ("trunk_positions", C.c_int64 * 3)]
 
 
 def build(force: bool = False) -> str:

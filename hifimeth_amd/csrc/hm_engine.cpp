@@ -90,7 +90,7 @@ struct PinnedArr {
     }
 };
 
-enum Kind { K_PREP, K_SCAN, K_EMIT, K_PACK, K_WINDOW, K_FRONT, K_TAIL, K_TRUNK, K_EDGE, K_TAILG, K_CONV5 };
+enum Kind { K_PREP, K_SCAN, K_EMIT, K_PACK, K_WINDOW, K_FRONT, K_TAIL, K_TRUNK, K_EDGE, K_TAILG };
 
 struct TimedSpan {
     int kind, ctx;
@@ -175,8 +175,6 @@ struct hm_engine {
     // scratch shared by all batches: only touched by kernels on the compute stream, which runs batches in order
     DevBuf d_act4, d_win, d_dbg, d_stamps;
     DevBuf d_map[3], d_e4, d_edge4, d_e4row, d_zeros;  // dense trunk: maps of one read group, edge rows of its sites
-    DevBuf d_c5;         // conv5 rows of the group's sites (split tail)
-    int tail5 = 1;       // 1 = conv5 as its own weight-stationary kernel + tail from conv6 (hm_tail6.hip), 0 = fused gathering tail
 
     std::vector<hipEvent_t> pool;
     hm_timing_t acc{};
@@ -253,7 +251,6 @@ void collect_timing(hm_engine* e, std::vector<TimedSpan>& spans, const int32_t* 
         case K_TRUNK: t.trunk_ms[s.ctx] += ms; ++t.trunk_launches[s.ctx]; t.trunk_positions[s.ctx] += s.cap; break;
         case K_EDGE: t.edge_ms[s.ctx] += ms; ++t.edge_launches[s.ctx]; break;
         case K_TAILG: t.tail_ms[s.ctx] += ms; ++t.tail_launches[s.ctx]; break;
-        case K_CONV5: t.conv5_ms[s.ctx] += ms; ++t.conv5_launches[s.ctx]; break;
         case K_FRONT:
             if (n > 0) { t.front_ms[s.ctx] += ms; ++t.front_launches[s.ctx]; t.front_sites[s.ctx] += n; }
             else { t.empty_ms += ms; ++t.empty_launches; }
@@ -516,7 +513,6 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
     e->d_e4.reserve((size_t)max_rows * 2 * C4_CH * sizeof(float));
     e->d_edge4.reserve((size_t)max_bases * 2 * C4_CH * sizeof(float));
     e->d_e4row.reserve((size_t)max_bases * sizeof(int32_t));
-    if (e->tail5) e->d_c5.reserve((size_t)max_bases * 13 * 2 * C4_CH * sizeof(uint16_t));
     if (!e->d_zeros.p) {
         e->d_zeros.reserve(1024);
         HIP_TRY(hipMemsetAsync(e->d_zeros.p, 0, 1024, e->stream));
@@ -545,18 +541,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
                             maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(), e->num_cu, w16);
                 sp.end();
             }
-            if (e->tail5) {
-                {
-                    Span sp(e, spans, K_CONV5, c);
-                    launch_conv5_ws(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
-                                    e->d_c5.as<uint16_t>(), e->num_cu, w16);
-                    sp.end();
-                }
-                Span sp(e, spans, K_TAILG, c);
-                launch_tail6(e->stream, sr, dm.w, maps, e->d_c5.as<uint16_t>(), b->d_logits.as<float>(), b->d_p.as<float>(),
-                             b->d_ml.as<uint8_t>(), e->num_cu, e->precision >= 2);
-                sp.end();
-            } else {
+            {
                 Span sp(e, spans, K_TAILG, c);
                 launch_tail_gather(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
                                    b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu, e->precision - 1);
@@ -728,7 +713,7 @@ void hm_destroy(hm_engine_t* e) {
     e->slots.clear();
     for (auto& m : e->model) m.params.release();
     for (DevBuf* b : {&e->d_act4, &e->d_win, &e->d_dbg, &e->d_stamps, &e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4,
-                      &e->d_edge4, &e->d_e4row, &e->d_zeros, &e->d_c5})
+                      &e->d_edge4, &e->d_e4row, &e->d_zeros})
         b->release();
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -768,8 +753,6 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
         if (value < 0 || value > 2) return fail(e, HM_EINVAL, "trunk must be 0 (per site), 1 (dense trunk) or 2 (by site density)");
         e->trunk = (int)value;
         for (double& d : e->density) d = -1;
-    } else if (k == "tail5") {
-        e->tail5 = value != 0;
     } else if (k == "group_bases") {
         if (value < 1) return fail(e, HM_EINVAL, "group_bases must be positive");
         e->group_bases = value;

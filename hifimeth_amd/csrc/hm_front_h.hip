@@ -410,6 +410,10 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
     constexpr int S = T::S, NW = 8;
     const Site* sites;
     const int n_sites = resolve_sites(sr, sites);
+    // A workgroup takes a CONTIGUOUS range of 8-site groups: neighbouring sites read the same E4 rows (a row serves the ~3
+    // sites whose windows sample it), so they come from this CU's L1 / its XCD's L2 instead of HBM again.
+    const int n_groups = (n_sites + S - 1) / S, base_n = n_groups / (int)gridDim.x, rem_n = n_groups - base_n * (int)gridDim.x;
+    const int g_begin = (int)blockIdx.x * base_n + min((int)blockIdx.x, rem_n), g_end = g_begin + base_n + ((int)blockIdx.x < rem_n);
     __shared__ __attribute__((aligned(16))) half_t smem[T::LDS_HALVES];
     half_t* h0 = smem;
     half_t* l0 = smem + T::P0;
@@ -510,26 +514,26 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
 
     // first group of this workgroup: staged by everybody
     if constexpr (GATHER) {
-        if ((int)threadIdx.x < S) s_row[0][threadIdx.x] = load_row(blockIdx.x, threadIdx.x);
+        if ((int)threadIdx.x < S) s_row[0][threadIdx.x] = load_row(g_begin, threadIdx.x);
         __syncthreads();
-        if (wave == 7) pend = load_row(blockIdx.x + gridDim.x, threadIdx.x - 448);
+        if (wave == 7) pend = load_row(g_begin + 1, threadIdx.x - 448);
     }
-    if ((int)blockIdx.x * S < n_sites) {
+    if (g_begin < g_end) {
         if constexpr (GATHER) {
-            stage_range(blockIdx.x, 0, 0, PIECES, 0, NW, 0);
-            stage_range(blockIdx.x, 1, 0, PIECES, 0, NW, 0);
+            stage_range(g_begin, 0, 0, PIECES, 0, NW, 0);
+            stage_range(g_begin, 1, 0, PIECES, 0, NW, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA is invisible to the compiler's own wait counting
         } else {
             for (int i = threadIdx.x; i < S * Q4; i += NW * 64) {
-                const float* src = elem_src(blockIdx.x, i, 0);
+                const float* src = elem_src(g_begin, i, 0);
                 put_elem(i, src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f));
             }
             zero_in_pads(0, S, threadIdx.x, NW * 64);
         }
     }
-    int slot = 0, g_first = blockIdx.x;  // groups g_first, g_first + gridDim.x, ... wait in ring slots 0 .. slot-1
-    for (int g = blockIdx.x; g * S < n_sites; g += gridDim.x) {
-        const bool more = (g + (int)gridDim.x) * S < n_sites;
+    int slot = 0, g_first = g_begin;  // groups g_first, g_first + 1, ... wait in ring slots 0 .. slot-1
+    for (int g = g_begin; g < g_end; ++g) {
+        const bool more = g + 1 < g_end;
         if constexpr (GATHER) {  // map rows of group g + grid (requested one iteration ago) -> LDS
             ++it;
             if (wave == 7 && (int)threadIdx.x - 448 < S) s_row[it & 1][threadIdx.x - 448] = pend;
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         // (explicit if / else on the wave id, not a call that returns early: the staged rows must not be live across
         //  the other waves' conv code or they spill)
         if (GATHER && wave >= 6) {  // spare in conv6: the hi plane's pieces behind conv6's output, by LDS-DMA
-            if (more) stage_range(g + gridDim.x, 0, LOW_PIECES, PIECES, 6, 2, it & 1);
+            if (more) stage_range(g + 1, 0, LOW_PIECES, PIECES, 6, 2, it & 1);
         } else if (wave >= 6) {  // spare in conv6: request sites 3..7 of the next group
             if (more) {
                 int tl = threadIdx.x;
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
 #pragma unroll
                 for (int k = 0; k < NHI; ++k) {
                     const int i = SPLIT_SITE * Q4 + tl - 384 + k * 128;
-                    const float* src = i < S * Q4 ? elem_src(g + gridDim.x, i, it & 1) : nullptr;
+                    const float* src = i < S * Q4 ? elem_src(g + 1, i, it & 1) : nullptr;
                     phi[k] = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         if (dbg && dbg_layer == 6 && g == 0) dump_planes<T::L6, 96, T::RS96>(h0, l0, dbg);
 
         if (GATHER && wave >= 4) {  // spare in conv7: the same pieces of the lo plane
-            if (more) stage_range(g + gridDim.x, 1, LOW_PIECES, PIECES, 4, 4, it & 1);
+            if (more) stage_range(g + 1, 1, LOW_PIECES, PIECES, 4, 4, it & 1);
         } else if (wave >= 6) {  // spare in conv7: the requested rows -> buffer 0 (behind conv6's output)
             if (more) {
                 int tl = threadIdx.x;
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
 #pragma unroll
                 for (int k = 0; k < NLO; ++k) {
                     const int i = tl - 256 + k * 128;
-                    const float* src = i < SPLIT_SITE * Q4 ? elem_src(g + gridDim.x, i, it & 1) : nullptr;
+                    const float* src = i < SPLIT_SITE * Q4 ? elem_src(g + 1, i, it & 1) : nullptr;
                     plo[k] = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             } else {
@@ -614,10 +618,10 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
 
         if (GATHER && wave >= 4) {  // spare in conv8: the pieces that held conv6's output (dead since the last barrier)
             if (more) {
-                stage_range(g + gridDim.x, 0, 0, LOW_PIECES, 4, 4, it & 1);
-                stage_range(g + gridDim.x, 1, 0, LOW_PIECES, 4, 4, it & 1);
+                stage_range(g + 1, 0, 0, LOW_PIECES, 4, 4, it & 1);
+                stage_range(g + 1, 1, 0, LOW_PIECES, 4, 4, it & 1);
             }
-            if (wave == 7) pend = load_row(g + 2 * (int)gridDim.x, threadIdx.x - 448);
+            if (wave == 7) pend = load_row(g + 2, threadIdx.x - 448);
             // everything this wave staged for the next group is in LDS before it reaches the barrier in front of conv5
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (wave >= 4) {
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
             sum += fc2w[512 + o];
             const float other = __shfl_xor(sum, 8, 64);
             const int sl = bsite / S, site = bsite - sl * S;
-            const int gs0 = (g_first + sl * (int)gridDim.x) * S;
+            const int gs0 = (g_first + sl) * S;
             if ((threadIdx.x & 15) == 0 && sl < slot && gs0 + site < n_sites) {
                 const float v0 = sum, v1 = other;
                 const float mx = fmaxf(v0, v1);

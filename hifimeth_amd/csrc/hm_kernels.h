@@ -71,12 +71,6 @@ void launch_edge(hipStream_t st, int k1, const SiteRange& sr, const RInfo* rinfo
                  bool w16);
 void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
                         const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, int w16_level);
-// the per-site layers behind the trunk as two kernels (hm_tail6.hip): weight-stationary conv5 -> c5[site][13][hi 96 | lo 96],
-// then conv6 .. fc2 from those rows
-void launch_conv5_ws(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
-                     const int32_t* e4row, uint16_t* c5, int grid, bool w16);
-void launch_tail6(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* c5,
-                  float* logits, float* p, uint8_t* ml, int grid, bool w16);
 size_t trunk_lds_bytes();
 
 size_t front_lds_bytes(int k1);

@@ -77,8 +77,6 @@ typedef struct {
     double trunk_ms[3], edge_ms[3]; /* dense trunk (conv1..conv4 over whole reads) and window-edge kernels */
     int64_t trunk_launches[3], edge_launches[3];
     int64_t trunk_positions[3]; /* (read, strand view) positions evaluated by the timed trunk launches */
-    double conv5_ms[3];         /* conv5 as its own weight-stationary kernel (option "tail5") */
-    int64_t conv5_launches[3];
 } hm_timing_t;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
@@ -94,8 +92,7 @@ const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a fa
  * network where they hold BASELINE.json configs[4]'s bar |dp| <= 1e-3 (tools/w16_error_table.py); 3 = fp16 weights in
  * conv2..conv8, the literal configs[4], which misses that bar (max |dp| ~ 2.5e-3): kept for the record; activations stay
  * split and accumulation fp32 in every mode), "trunk" (1 = conv1..conv4 once per read position, default; 0 = once per
- * site), "group_bases" (reads per trunk group, default 2 Mi bases), "tail5" (1 = conv5 as a weight-stationary kernel of
- * its own + tail from conv6, default; 0 = one fused tail kernel gathering conv4 rows), "stamps" (diagnostic) */
+ * site), "group_bases" (reads per trunk group, default 2 Mi bases), "stamps" (diagnostic) */
 int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
 
 /* ---- staging: the EvalKmerFeaturesGenerator::init seam ----------------------------------- */
