@@ -200,6 +200,32 @@ def test_cli_call_sharded_over_ranks_matches_single_rank(tmp_path):
     assert subprocess.call([CLI, "call", "--nonsense"], stderr=subprocess.DEVNULL) != 0
 
 
+@pytest.mark.gpu
+def test_call_dist_two_ranks_launched_like_a_multi_gpu_job(tmp_path):
+    """python -m torch.distributed.run --nproc-per-node 2 -m hifimeth_amd.call_dist: one process per rank, each calls its
+    BGZF-offset shard through the native front end (both on this box's one GPU; gloo for the barrier), rank 0 merges.
+    Records equal the single-process run."""
+    import socket
+    import sys
+    reads = synth_reads(24, seed=77, median_len=5000, sigma=0.4, frac_wide=0.1, frac_short=0.1, frac_missing=0.1)
+    src, one, two = str(tmp_path / "in.bam"), str(tmp_path / "one.bam"), str(tmp_path / "two.bam")
+    bamutil.reads_to_bam(src, reads, level=1)
+    subprocess.check_call([CLI, "call", "-t", "4", src, one], stderr=subprocess.DEVNULL)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, HM_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), "-m", "hifimeth_amd.call_dist", "-t", "4", src, two],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    _, a = bamutil.read_bam(one)
+    _, b = bamutil.read_bam(two)
+    assert len(a) == len(b) == len(reads)
+    for x, y in zip(a, b):
+        assert x["name"] == y["name"] and x["aux"] == y["aux"]
+
+
 def _modstats(path):
     import json
     return json.loads(subprocess.check_output([CLI, "modstats", path]))

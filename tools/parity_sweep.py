@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off larger parity sweep: GPU calls vs the CPU oracle over N synthetic reads (all contexts), several seeds.
-usage: parity_sweep.py [reads_per_seed] [seeds]"""
+usage: parity_sweep.py [reads_per_seed] [seeds] [engine option=value ...]   (e.g. trunk=0 precision=2)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -15,7 +15,11 @@ O.build()
 models = [O.Model(os.path.join(ROOT, "hifimeth_amd", "weights", c + ".hmw")) for c in ("CpG", "CHG", "CHH")]
 worst, total, nml, t0 = 0.0, 0, 0, time.time()
 hist = np.zeros(8, np.int64)   # |dp| decades 1e-9..1e-2
+opts = [a.split("=") for a in sys.argv[3:]]
+print("engine options:", opts or "defaults (dense trunk, split-half fp16x3)")
 with MethylationCaller(device=0) as mc:
+    for k, v in opts:
+        mc.set_option(k, int(v))
     for seed in range(seeds):
         reads = synth_reads(n, seed=1000 + seed, gc=(0.36, 0.41, 0.5)[seed % 3])
         calls = mc.call(reads)
