@@ -527,14 +527,33 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
             if (!(ctx_mask >> c & 1)) continue;
             const DeviceModel& dm = e->model[c];
             const int n_views = c == CHH ? 2 : 1;  // CpG / CHG are called on the forward strand only (eval_kmer_features.cpp:89-126)
+            const SiteRange sr{b->d_csites.as<Site>(), b->d_totals.as<int32_t>(), c, 0, (int32_t)std::min<int64_t>(g.bases, INT32_MAX),
+                               offs + (size_t)NCNT * g.chunk_lo + c, offs + (size_t)NCNT * g.chunk_hi + c};
+            if (e->precision == 0) {  // strict fp32: the same three steps on fp32 maps (hm_trunk_f32.hip)
+                {
+                    Span sp(e, spans, K_TRUNK, c, 0, (int64_t)n_tiles * TR_OWN * n_views);
+                    launch_trunk_f32(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
+                                     b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->num_cu);
+                    sp.end();
+                }
+                {
+                    Span sp(e, spans, K_EDGE, c);
+                    launch_edge_f32(e->stream, dm.k1, sr, b->d_rinfo.as<RInfo>(), b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), dm.w,
+                                    maps, e->d_edge4.as<float>(), e->d_e4row.as<int32_t>(), e->num_cu);
+                    sp.end();
+                }
+                Span sp(e, spans, K_TAILG, c);
+                launch_tail_gather_f32(e->stream, sr, dm.w, maps, e->d_edge4.as<float>(), e->d_e4row.as<int32_t>(),
+                                       b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu);
+                sp.end();
+                continue;
+            }
             {
                 Span sp(e, spans, K_TRUNK, c, 0, (int64_t)n_tiles * TR_OWN * n_views);
                 launch_trunk(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
                              b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->num_cu, w16);
                 sp.end();
             }
-            const SiteRange sr{b->d_csites.as<Site>(), b->d_totals.as<int32_t>(), c, 0, (int32_t)std::min<int64_t>(g.bases, INT32_MAX),
-                               offs + (size_t)NCNT * g.chunk_lo + c, offs + (size_t)NCNT * g.chunk_hi + c};
             {
                 Span sp(e, spans, K_EDGE, c);
                 launch_edge(e->stream, dm.k1, sr, b->d_rinfo.as<RInfo>(), b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), dm.w,
@@ -577,7 +596,7 @@ void enqueue_run(hm_batch* b) {
         sp.end();
     }
     int trunk_mask = 0;  // contexts whose conv1..conv4 run as the dense trunk
-    if (e->precision >= 1 && e->trunk)
+    if (e->trunk)
         for (int c = 0; c < 3; ++c) {
             const double thr = c == CHH ? 0.033 : 0.017;
             if ((e->ctx_mask >> c & 1) && (e->trunk == 1 || e->density[c] < 0 || e->density[c] >= thr)) trunk_mask |= 1 << c;

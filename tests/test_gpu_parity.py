@@ -17,11 +17,12 @@ pytestmark = pytest.mark.gpu
 DP_TOL = 1e-4  # north_star: |dp| <= 1e-4 vs the fp32 CPU path
 
 
-@pytest.fixture(scope="module", params=[(1, 1), (1, 0), (0, 0)], ids=["trunk-f16x3", "persite-f16x3", "persite-fp32"])
+@pytest.fixture(scope="module", params=[(1, 1), (1, 0), (0, 1), (0, 0)],
+                ids=["trunk-f16x3", "persite-f16x3", "trunk-fp32", "persite-fp32"])
 def mc(request):
-    """Every parity test runs in three modes: the default (conv1..conv4 as a dense trunk over every read position,
+    """Every parity test runs in four modes: the default (conv1..conv4 as a dense trunk over every read position,
     split-half fp16 MFMA with fp32 accumulation), the same arithmetic with conv1..conv4 per site (front kernels), and
-    per site on plain fp32 MFMA.  All must meet the same |dp| <= 1e-4 bar."""
+    both layouts again on plain fp32 MFMA.  All must meet the same |dp| <= 1e-4 bar."""
     from hifimeth_amd import MethylationCaller
     m = MethylationCaller(device=0, timing=True)
     m.set_option("precision", request.param[0])
