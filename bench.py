@@ -240,13 +240,25 @@ def main():
             torch.cuda.synchronize()
             d32 = time.perf_counter() - t1
             t32 = mc.timing()
-            f_ms = sum(t32["front_ms"])
-            fl = sum(2.0 * MAC_FRONT[c] * t32["front_sites"][c] for c in range(3))
-            ach = fl / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
-            extras["fp32_mode"] = {"value": sum(s32) / d32, "unit": "sites/s", "steps": k32, "dtype": "f32",
-                                   "kernel": "front_kernel (v_mfma_f32_16x16x4_f32)", "achieved": ach,
-                                   "peak": PEAK_FP32_MFMA_TFLOPS, "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                                   "note": "same streamed workload, engine option precision=0"}
+            f_ms, tr_ms = sum(t32["front_ms"]), sum(t32["trunk_ms"])
+            fp32 = {"value": sum(s32) / d32, "unit": "sites/s", "steps": k32, "dtype": "f32", "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "note": "same streamed workload, engine option precision=0"}
+            if tr_ms > 0:
+                # dense trunk in strict fp32 (hm_trunk_f32.hip): `achieved` as in the headline roofline = the reference's
+                # conv1..conv4 FLOPs for the sites served / kernel time; `executed` = 2048 FLOP per v_mfma_f32_16x16x4_f32,
+                # per 112-position tile 9 / 9 / 8 / 7 position tiles x 8 / 8 / 8 / 6 channel tiles x K / 4 steps
+                k1g = {0: 24, 1: 24, 2: 28}
+                mf = {c: 9 * 8 * k1g[c] + (9 + 8) * 8 * 96 + 7 * 6 * 96 for c in range(3)}
+                ach = sum(2.0 * MAC_FRONT[c] * s32[c] for c in range(3)) / (tr_ms * 1e-3) / 1e12
+                ex = sum(t32["trunk_positions"][c] / 112.0 * mf[c] * 2048.0 for c in range(3)) / (tr_ms * 1e-3) / 1e12
+                fp32.update({"kernel": "trunk_kernel_f32 (v_mfma_f32_16x16x4_f32)", "achieved": ach, "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                             "executed": ex, "frac_executed": ex / PEAK_FP32_MFMA_TFLOPS,
+                             "device_ms": {"trunk_ms": tr_ms, "edge_ms": sum(t32["edge_ms"]), "tail_ms": sum(t32["tail_ms"])}})
+            else:
+                fl = sum(2.0 * MAC_FRONT[c] * t32["front_sites"][c] for c in range(3))
+                ach = fl / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0
+                fp32.update({"kernel": "front_kernel (v_mfma_f32_16x16x4_f32)", "achieved": ach, "frac": ach / PEAK_FP32_MFMA_TFLOPS})
+            extras["fp32_mode"] = fp32
             mc.set_option("precision", args.precision)
 
     if rank == 0:

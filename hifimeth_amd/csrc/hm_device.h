@@ -85,6 +85,7 @@ struct TrunkMaps {
     uint16_t* e4;       // E4: [2 views][rows][hi 96 | lo 96] fp16 halves (what the tail's input planes hold)
     int64_t view_rows;  // rows per view
     const uint16_t* zeros;  // >= 16 zero bytes (source of padding for the tail's LDS-DMA gather)
+    uint8_t* rowlist;   // [tile x view][3][TR_OWN]: per layer the tile rows an edge chain reads, padded with row 0 (rowlist_kernel)
 };
 
 // bn0 folded into lookup tables, computed on the host with the ONNX BatchNormalization

@@ -158,6 +158,7 @@ struct hm_engine {
     // so the trunk wins above ~1.7 % sites per base (CHH, two views: 3.3 %) -- everything but CpG-only runs on
     // CpG-poor genomes.  Both paths give the same calls to within fp32 re-association.
     int trunk = 2;
+    int trunk_impl = 1;  // 1: streaming 4-wave trunk kernel (hm_convs.h), 0: the 8-wave ConvH form
     double density[3] = {-1, -1, -1};  // sites per base of the last finished batch (-1: none yet -> trunk)
     int64_t group_bases = int64_t(2) << 20;  // reads per trunk group: their maps take ~3.9 KB per base
     bool stamps_on = false;
@@ -174,7 +175,7 @@ struct hm_engine {
 
     // scratch shared by all batches: only touched by kernels on the compute stream, which runs batches in order
     DevBuf d_act4, d_win, d_dbg, d_stamps;
-    DevBuf d_map[3], d_e4, d_edge4, d_e4row, d_zeros;  // dense trunk: maps of one read group, edge rows of its sites
+    DevBuf d_map[3], d_e4, d_edge4, d_e4row, d_zeros, d_rowlist;  // dense trunk: maps of one read group, edge rows of its sites
 
     std::vector<hipEvent_t> pool;
     hm_timing_t acc{};
@@ -511,6 +512,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
     }
     for (int i = 0; i < 3; ++i) e->d_map[i].reserve((size_t)max_rows * 2 * 256 * sizeof(uint16_t));
     e->d_e4.reserve((size_t)max_rows * 2 * C4_CH * sizeof(float));
+    e->d_rowlist.reserve((size_t)(max_rows / TR_OWN + 1) * 2 * 3 * TR_OWN);
     e->d_edge4.reserve((size_t)max_bases * 2 * C4_CH * sizeof(float));
     e->d_e4row.reserve((size_t)max_bases * sizeof(int32_t));
     if (!e->d_zeros.p) {
@@ -521,7 +523,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
     const int32_t* offs = b->d_offs.as<int32_t>();
     for (const auto& g : b->groups) {
         const TrunkMaps maps{{e->d_map[0].as<uint16_t>(), e->d_map[1].as<uint16_t>(), e->d_map[2].as<uint16_t>()},
-                             e->d_e4.as<uint16_t>(), g.rows, e->d_zeros.as<uint16_t>()};
+                             e->d_e4.as<uint16_t>(), g.rows, e->d_zeros.as<uint16_t>(), e->d_rowlist.as<uint8_t>()};
         const int n_tiles = g.tile_hi - g.tile_lo;
         for (int c = 0; c < 3; ++c) {
             if (!(ctx_mask >> c & 1)) continue;
@@ -550,7 +552,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
             }
             {
                 Span sp(e, spans, K_TRUNK, c, 0, (int64_t)n_tiles * TR_OWN * n_views);
-                launch_trunk(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
+                (e->trunk_impl ? launch_trunk2 : launch_trunk)(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
                              b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->num_cu, w16);
                 sp.end();
             }
@@ -731,7 +733,7 @@ void hm_destroy(hm_engine_t* e) {
     for (auto& b : e->slots) free_slot(b.get());
     e->slots.clear();
     for (auto& m : e->model) m.params.release();
-    for (DevBuf* b : {&e->d_act4, &e->d_win, &e->d_dbg, &e->d_stamps, &e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4,
+    for (DevBuf* b : {&e->d_act4, &e->d_win, &e->d_dbg, &e->d_stamps, &e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4, &e->d_rowlist,
                       &e->d_edge4, &e->d_e4row, &e->d_zeros})
         b->release();
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
@@ -772,6 +774,9 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
         if (value < 0 || value > 2) return fail(e, HM_EINVAL, "trunk must be 0 (per site), 1 (dense trunk) or 2 (by site density)");
         e->trunk = (int)value;
         for (double& d : e->density) d = -1;
+    } else if (k == "trunk_impl") {
+        if (value < 0 || value > 1) return HM_EINVAL;
+        e->trunk_impl = (int)value;
     } else if (k == "group_bases") {
         if (value < 1) return fail(e, HM_EINVAL, "group_bases must be positive");
         e->group_bases = value;

@@ -19,6 +19,19 @@
 //
 // Reference for what is computed: training/model_cnn.py:8-85 / models/*.onnx (mod_main.cpp:32-98).
 #include "hm_convh.h"
+#include "hm_convs.h"
+#ifdef HM_TRUNK_STAMP  // diagnostic build (make stamp): per-wave shader-clock phase sums of workgroup 0, read by tools/trunk_stamps.py
+#include "hm_stamp.h"
+namespace hm { __device__ unsigned long long g_trunk_stamp[8][24]; }
+extern "C" int hm_debug_trunk_stamps(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(hm::g_trunk_stamp), sizeof(hm::g_trunk_stamp)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[8][24];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(hm::g_trunk_stamp), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 namespace hm {
 
@@ -31,6 +44,9 @@ constexpr int TR_WRS = 8;      // feature row = 8 exact halves
 constexpr int TR_AROWS = 148, TR_BROWS = 144;
 static_assert(TR_M1 + 4 <= TR_AROWS && TR_M3 + 8 <= TR_BROWS && TR_M4 + 16 <= TR_M3, "halo plan");
 constexpr int TR_LDS_HALVES = 2 * TR_AROWS * TR_RS + 2 * TR_BROWS * TR_RS;
+constexpr int TR_CS = TR_OWN / 8;   // streaming trunk: copy slots per wave and layer: 4 waves x 2 rows x 14 = every own row of the tile
+constexpr int TR_RL = 3 * TR_OWN;   // bytes of a tile's row lists (rowlist_kernel)
+static_assert(TR_OWN % 8 == 0 && TR_RL % 4 == 0, "row lists");
 
 // ReLU + split -> LDS planes (row m, no padding rows: the dense form has none); the rows an edge chain will read also
 // go to the HBM map as [hi 128 | lo 128].  (Measured: all map stores together cost 11 % of the kernel.  Staging them in
@@ -168,29 +184,341 @@ __global__ __launch_bounds__(512) void trunk_kernel(const TrunkTile* __restrict_
 
     // conv1: folded bn0, exact fp16 operand, weights' hi / lo halves stacked along K; dense: every position, taps 1 row apart
     using C1 = ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, TR_M1, TR_WRS, 1, 8, 4, 1, 0, 0, true, false, false, K1, true, 0, 1, 1>;
-    using C2 = ConvH<NW, 128, 3, 128, TR_M2, TR_RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 1, 1, 2>;
-    using C3 = ConvH<NW, 128, 3, 128, TR_M3, TR_RS, 1, 8, 3, 1, 0, 0, !W16, true, false, 0, true, 1, 1, 4>;
-    using C4 = ConvH<NW, 128, 3, C4_CH, TR_M4, TR_RS, 1, 6, 3, 1, 0, 0, !W16, true, false, 0, true, 1, 1, 8>;
+#ifndef TRK_WM
+#define TRK_WM 1
+#define TRK_WN 8
+#define TRK_BR 3
+#define TRK_BR4 3
+#endif
+    using C2 = ConvH<NW, 128, 3, 128, TR_M2, TR_RS, TRK_WM, TRK_WN, TRK_BR, 1, 0, 0, !W16, true, false, 0, true, 1, 1, 2>;
+    using C3 = ConvH<NW, 128, 3, 128, TR_M3, TR_RS, TRK_WM, TRK_WN, TRK_BR, 1, 0, 0, !W16, true, false, 0, true, 1, 1, 4>;
+    using C4 = ConvH<NW, 128, 3, C4_CH, TR_M4, TR_RS, 1, 6, TRK_BR4, 1, 0, 0, !W16, true, false, 0, true, 1, 1, 8>;
     auto wf = [&](int i) { return reinterpret_cast<const half_t*>(W.wfrag_h[i]); };
 
     if ((int)blockIdx.x < n_work) build(blockIdx.x, threadIdx.x, NW * 64);
+#ifdef HM_TRUNK_STAMP
+    // phases per layer: [0] barrier -> prologue loads issued, [1] k-loop, [2] epilogue, [3] wait at the next barrier
+    unsigned long long ts[20], acc_t[16] = {};
+    unsigned long long n_it = 0;
+    const bool st_on = blockIdx.x == 0;
+#define TS(i) do { if (st_on) ts[i] = hm_stamp(); } while (0)
+#define MK(l) [&](int i) __attribute__((always_inline)) { if (st_on) ts[4 * (l) + 1 + i] = hm_stamp(); }
+#else
+#define TS(i)
+#define MK(l) typename C2::NoMark{}
+#endif
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         __syncthreads();  // feature rows, flags and the map row of this tile are in LDS; the previous conv4 is done with planes A
+        TS(0);
         const int64_t grow0 = s_grow0;
         half_t* g1 = reinterpret_cast<half_t*>(mp.e[0]) + (size_t)grow0 * 256;
         half_t* g2 = reinterpret_cast<half_t*>(mp.e[1]) + (size_t)grow0 * 256;
         half_t* g3 = reinterpret_cast<half_t*>(mp.e[2]) + (size_t)grow0 * 256;
-        C1::run(b_hi, b_hi, reinterpret_cast<const half_t*>(W.c1f), EpiTrunk<0>{a_hi, a_lo, W.c1f_bias, flags, g1});
+        C1::run(b_hi, b_hi, reinterpret_cast<const half_t*>(W.c1f), EpiTrunk<0>{a_hi, a_lo, W.c1f_bias, flags, g1}, MK(0));
+        TS(3);
         __syncthreads();
-        C2::run(a_hi, a_lo, wf(1), EpiTrunk<1>{b_hi, b_lo, W.bias[1], flags, g2});
+        TS(4);
+        C2::run(a_hi, a_lo, wf(1), EpiTrunk<1>{b_hi, b_lo, W.bias[1], flags, g2}, MK(1));
+        TS(7);
         __syncthreads();
-        C3::run(b_hi, b_lo, wf(2), EpiTrunk<2>{a_hi, a_lo, W.bias[2], flags, g3});
+        TS(8);
+        C3::run(b_hi, b_lo, wf(2), EpiTrunk<2>{a_hi, a_lo, W.bias[2], flags, g3}, MK(2));
+        TS(11);
         __syncthreads();
+        TS(12);
         // conv4 on 6 waves (96 channels); the other two build the next tile's feature rows in planes B meanwhile
-        C4::run(a_hi, a_lo, wf(3), EpiE4{reinterpret_cast<half_t*>(mp.e4) + (size_t)grow0 * (2 * C4_CH), W.bias[3]});
+        C4::run(a_hi, a_lo, wf(3), EpiE4{reinterpret_cast<half_t*>(mp.e4) + (size_t)grow0 * (2 * C4_CH), W.bias[3]}, MK(3));
         const int wn = w + gridDim.x;
         if (wn < n_work && (int)threadIdx.x >= 384) build(wn, threadIdx.x - 384, 128);
+        TS(15);
+#ifdef HM_TRUNK_STAMP
+        if (st_on) {
+            __syncthreads();
+            ts[16] = hm_stamp();
+            const bool c4w = threadIdx.x < 384;
+            for (int l = 0; l < 4; ++l) {
+                if (l == 3 && !c4w) { acc_t[12] += ts[15] - ts[12]; acc_t[15] += ts[16] - ts[15]; continue; }
+                acc_t[4 * l + 0] += ts[4 * l + 1] - ts[4 * l];
+                acc_t[4 * l + 1] += ts[4 * l + 2] - ts[4 * l + 1];
+                acc_t[4 * l + 2] += ts[4 * l + 3] - ts[4 * l + 2];
+                acc_t[4 * l + 3] += ts[4 * l + 4] - ts[4 * l + 3];
+            }
+            ++n_it;
+        }
+#endif
     }
+#ifdef HM_TRUNK_STAMP
+    if (st_on && (threadIdx.x & 63) == 0) {
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_trunk_stamp[threadIdx.x >> 6][i], acc_t[i]);
+        atomicAdd(&g_trunk_stamp[threadIdx.x >> 6][16], n_it);
+    }
+#endif
+#undef TS
+#undef MK
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Which map rows do the edge chains read?  Per tile and view, for each of E1..E3 a list of TR_OWN tile rows: the flagged ones
+// first, the rest filled with row 0 (storing a valid row once more is harmless), so that the streaming trunk copies
+// "every list entry" with no count and no branch.
+template <int K1>
+__global__ __launch_bounds__(128) void rowlist_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int ctx,
+                                                       const RInfo* __restrict__ rinfo, const uint8_t* __restrict__ bases,
+                                                       const uint8_t* __restrict__ sctx, uint8_t* __restrict__ rowlist) {
+    using G = EdgeGeo<K1>;
+    __shared__ int cnt0[3];
+    const int w = blockIdx.x, view = w >= n_tiles, r = threadIdx.x;
+    const TrunkTile tl = tiles[view ? w - n_tiles : w];
+    const RInfo ri = rinfo[tl.read_idx];
+    const int L = ri.len, x = tl.u0 + r, want_base = view ? 2 : 1;
+    auto site_at = [&](int y) __attribute__((always_inline)) {
+        if (y < 0 || y >= L) return 0;
+        const int64_t j = ri.base_off + (view ? L - 1 - y : y);
+        return (int)(sctx[j] == ctx && bases[j] == want_base);
+    };
+    int f = 0;
+    if (r < TR_OWN) {
+        const int left = site_at(x - G::LEFT);
+        f |= (left | site_at(x - G::R1) | (G::PAD2 ? 0 : site_at(x - G::R1 - 2))) << 0;
+        f |= (left | site_at(x - G::R2) | (G::PAD3 ? 0 : site_at(x - G::R2 - 4))) << 1;
+        f |= (left | site_at(x - G::R3) | (G::PAD4 ? 0 : site_at(x - G::R3 - 8))) << 2;
+    }
+    uint8_t* out = rowlist + (size_t)w * TR_RL;
+    for (int i = r; i < TR_RL; i += 128) out[i] = 0;
+    uint64_t bal[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) bal[l] = __ballot((f >> l) & 1);
+    if (r < 3) cnt0[r] = 0;
+    __syncthreads();  // also orders the zero fill before the entries below (same block, global memory)
+    if (r == 0) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) cnt0[l] = __popcll(bal[l]);
+    }
+    __syncthreads();
+    const int lane = r & 63;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+        if ((f >> l) & 1) out[l * TR_OWN + (r >= 64 ? cnt0[l] : 0) + __popcll(bal[l] & ((1ull << lane) - 1))] = (uint8_t)r;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// trunk_kernel in the streaming form of hm_convs.h: 4 waves (one per SIMD), a wave owns 32 channels of a layer with its
+// weights resident in registers, the positions stream through in groups of tiles.  Same tiles, same LDS planes, same maps.
+namespace {
+
+struct EpiTrunkS {
+    half_t* hi;
+    half_t* lo;
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        half4 h, l;
+        split4(acc, h, l);
+        *reinterpret_cast<half4*>(hi + m * TR_RS + col) = h;
+        *reinterpret_cast<half4*>(lo + m * TR_RS + col) = l;
+    }
+};
+
+struct EpiE4S {
+    half_t* __restrict__ g;
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        half4 h, l;
+        split4(acc, h, l);
+        *reinterpret_cast<half4*>(g + (size_t)m * (2 * C4_CH) + col) = h;
+        *reinterpret_cast<half4*>(g + (size_t)m * (2 * C4_CH) + C4_CH + col) = l;
+    }
+};
+
+struct CopyRows3 {  // the same rows over three waves
+    static constexpr int CS = (TR_OWN / 2 + 2) / 3, NWV = 3;
+    const uint8_t* rows;
+    half_t* g;
+};
+struct CopyRows {
+    static constexpr int CS = TR_CS, NWV = 4;
+    const uint8_t* rows;  // LDS: this layer's list of TR_OWN row numbers
+    half_t* g;            // map row of tile row 0
+};
+
+}  // namespace
+
+template <int K1, bool W16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void trunk2_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views, int ctx, const RInfo* __restrict__ rinfo,
+                   const uint8_t* __restrict__ bases, const uint32_t* __restrict__ kin, const uint8_t* __restrict__ sctx,
+                   CtxWeights W, TrunkMaps mp) {
+    using G = EdgeGeo<K1>;
+    constexpr int NW = 4;
+    __shared__ __attribute__((aligned(16))) half_t smem[TR_LDS_HALVES + TR_XROWS * TR_WRS];
+    __shared__ uint32_t rlist[2][3 * 32];  // the tile's row lists ([3][128] bytes, entries past TR_OWN stay 0); two buffers: conv4
+                                          // still copies E3 rows while the next tile's arrive
+    __shared__ int64_t s_grow0;
+    half_t* a_hi = smem;
+    half_t* a_lo = a_hi + TR_AROWS * TR_RS;
+    half_t* b_hi = a_lo + TR_AROWS * TR_RS;
+    half_t* b_lo = b_hi + TR_BROWS * TR_RS;
+    half_t* xb = b_lo + TR_BROWS * TR_RS;  // feature rows of the tile (their own buffer: built while conv4 runs)
+    const int n_work = n_tiles * n_views;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    for (int i = threadIdx.x; i < (TR_AROWS - TR_M1) * TR_RS; i += NW * 64) {
+        a_hi[TR_M1 * TR_RS + i] = (half_t)0.f;
+        a_lo[TR_M1 * TR_RS + i] = (half_t)0.f;
+    }
+    if (threadIdx.x < 2 * 3 * 32) rlist[0][threadIdx.x] = 0;
+    __syncthreads();
+
+    // The next tile's feature rows and map-row flags, one row per thread, in three steps that sit between the layers so
+    // that no load's latency is exposed: (1) the tile and its read's descriptor, during conv1; (2) the row's base,
+    // kinetics and four bytes of its row lists (rowlist_kernel), before conv3 -- branch-free, from clamped addresses; (3) decode + LDS
+    // writes at the start of conv4.
+    struct Build {
+        TrunkTile tl;
+        RInfo ri;
+        int w, view, b;
+        uint32_t k, rl;
+    } bd;
+    // the descriptors are two dependent loads of wave-uniform values: each is issued one layer before its result is made
+    // scalar (readfirstlane), so that neither wait lands inside a layer's instruction stream
+    auto build_desc1 = [&](const int w) __attribute__((always_inline)) {
+        bd.w = w;
+        bd.view = w >= n_tiles;
+        bd.tl = tiles[bd.view ? w - n_tiles : w];
+    };
+    auto build_desc2 = [&]() __attribute__((always_inline)) {
+        bd.tl.read_idx = __builtin_amdgcn_readfirstlane(bd.tl.read_idx);
+        bd.tl.u0 = __builtin_amdgcn_readfirstlane(bd.tl.u0);
+        bd.ri = rinfo[bd.tl.read_idx];
+    };
+    auto build_desc3 = [&]() __attribute__((always_inline)) {
+        bd.ri.len = __builtin_amdgcn_readfirstlane(bd.ri.len);
+        bd.ri.map_off = __builtin_amdgcn_readfirstlane(bd.ri.map_off);
+        bd.ri.base_off = ((int64_t)__builtin_amdgcn_readfirstlane((int)(bd.ri.base_off >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)bd.ri.base_off);
+    };
+    auto grow_of = [&]() __attribute__((always_inline)) { return (int64_t)bd.view * mp.view_rows + bd.ri.map_off + (bd.tl.u0 + TR_PAD); };
+    auto build_loads = [&]() __attribute__((always_inline)) {
+        const int r = threadIdx.x, L = bd.ri.len, x = bd.tl.u0 + r;
+        const int xc = min(max(x, 0), L - 1);
+        const int64_t j = bd.ri.base_off + (bd.view ? L - 1 - xc : xc);
+        bd.b = bases[j];
+        bd.k = kin[j];
+        bd.rl = reinterpret_cast<const uint32_t*>(mp.rowlist + (size_t)bd.w * TR_RL)[min(r, TR_RL / 4 - 1)];
+    };
+    auto build_store = [&](const int buf) __attribute__((always_inline)) {
+        const int r = threadIdx.x, x = bd.tl.u0 + r;
+        if (r == 0) s_grow0 = grow_of();
+        if (r < TR_XROWS) {
+            const bool in = x >= 0 && x < bd.ri.len;
+            *reinterpret_cast<uint4*>(xb + r * TR_WRS) = feature_row(in ? bd.b : -1, bd.k, bd.view);
+        }
+        if (r < TR_RL / 4) rlist[buf][r / (TR_OWN / 4) * 32 + r % (TR_OWN / 4)] = bd.rl;
+    };
+
+#ifndef TRK2_XD
+#define TRK2_XD 1
+#endif
+    using C1 = SCfg<8, (2 * K1 + 3) / 4 * 4, TR_WRS, 1, true, false, K1, 3>;
+    using C2 = SCfg<128, 3, TR_RS, 2, !W16, true, 0, TRK2_XD>;
+    using C3 = SCfg<128, 3, TR_RS, 4, !W16, true, 0, TRK2_XD>;
+#ifndef TRK2_C4W4  // conv4 on three waves, two channel tiles each, all positions (three tiles x half the positions on four
+                  // waves needs 288 weight registers per wave and spills: scratch traffic shares the vector-memory counter)
+    using C4 = SCfg<128, 3, TR_RS, 8, !W16, true, 0, TRK2_XD, 2>;
+    using L4a = SConv<C4, C1, 0, 4, 3>;
+    using L4b = L4a;
+    const int nt04 = wave < 3 ? 2 * wave : 4;
+#else
+    using C4 = SCfg<128, 3, TR_RS, 8, !W16, true, 0, TRK2_XD, 3>;  // 96 channels: a wave takes 3 channel tiles x half the positions
+    using L4a = SConv<C4, C1, 0, 2, 2>;
+    using L4b = SConv<C4, C1, 4, 2, 1>;
+    const int nt04 = 3 * (wave & 1);
+#endif
+    using L1 = SConv<C1, C2, 0, 3, 3, 3>;
+    using L2 = SConv<C2, C3, 0, 3, 3, 3>;
+    using L3 = SConv<C3, C4, 0, 4, 4>;
+    static_assert(TR_M1 == 144 && TR_M2 == 144 && TR_M3 == 128 && TR_M4 == 112, "tile groups of the streaming layers");
+    static_assert(TR_XROWS <= NW * 64, "one feature row per thread");
+    auto wf = [&](int i) { return reinterpret_cast<const half_t*>(W.wfrag_h[i]); };
+    const half_t* c1f = reinterpret_cast<const half_t*>(W.c1f);
+    const int nt0 = 2 * wave;
+
+    WRegs wr;
+    sconv_load_w<C1, 0, C1::KB>(c1f, nt0, lane, wr);
+    sconv_load_bias<C1>(W.c1f_bias, nt0, lane, wr);
+    if ((int)blockIdx.x < n_work) {
+        build_desc1(blockIdx.x);
+        build_desc2();
+        build_desc3();
+        build_loads();
+        build_store(0);
+    }
+    int buf = 0;
+#ifdef HM_TRUNK_STAMP
+    // per layer: [0] barrier -> run returns, [3] wait at the next barrier
+    unsigned long long ts[10], acc_t[16] = {};
+    unsigned long long n_it = 0;
+    const bool st_on = blockIdx.x == 0;
+#define TS(i) do { if (st_on) ts[i] = hm_stamp(); } while (0)
+#else
+#define TS(i)
+#endif
+    for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+        __syncthreads();
+        TS(0);
+        const int64_t grow0 = s_grow0;
+        const int wn = w + gridDim.x;
+        half_t* g1 = reinterpret_cast<half_t*>(mp.e[0]) + (size_t)grow0 * 256;
+        half_t* g2 = reinterpret_cast<half_t*>(mp.e[1]) + (size_t)grow0 * 256;
+        half_t* g3 = reinterpret_cast<half_t*>(mp.e[2]) + (size_t)grow0 * 256;
+        const uint8_t* rl = reinterpret_cast<const uint8_t*>(rlist[buf]);
+        L1::run(xb, xb, wr, EpiTrunkS{a_hi, a_lo}, wf(1), W.bias[1], nt0, nt0);
+        build_desc1(min(wn, n_work - 1));  // unconditional (as are the loads below): the compiler's wait counts stay exact
+        TS(1);
+        __syncthreads();
+        TS(2);
+        build_desc2();
+        L2::run(a_hi, a_lo, wr, EpiTrunkS{b_hi, b_lo}, wf(2), W.bias[2], nt0, nt0, CopyRows{rl, g1});
+        TS(3);
+        __syncthreads();
+        TS(4);
+        build_desc3();
+        build_loads();
+        L3::run(b_hi, b_lo, wr, EpiTrunkS{a_hi, a_lo}, wf(3), W.bias[3], nt0, nt04, CopyRows{rl + 128, g2});
+        TS(5);
+        __syncthreads();
+        TS(6);
+        const EpiE4S e4{reinterpret_cast<half_t*>(mp.e4) + (size_t)grow0 * (2 * C4_CH)};
+#ifndef TRK2_C4W4
+        if (wave < 3) {
+            L4a::run(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0, CopyRows3{rl + 256, g3});
+        } else {
+            sconv_load_bias<C1>(W.c1f_bias, nt0, lane, wr);
+            sconv_load_w<C1, 0, C1::KB>(c1f, nt0, lane, wr);
+        }
+#else
+        if (wave < 2) L4a::run(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0, CopyRows{rl + 256, g3});
+        else L4b::run(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0, CopyRows{rl + 256, g3});
+#endif
+        build_store(buf ^ 1);
+        buf ^= 1;
+        TS(7);
+#ifdef HM_TRUNK_STAMP
+        if (st_on) {
+            __syncthreads();
+            ts[8] = hm_stamp();
+            for (int l = 0; l < 4; ++l) {
+                acc_t[4 * l + 0] += ts[2 * l + 1] - ts[2 * l];
+                acc_t[4 * l + 3] += ts[2 * l + 2] - ts[2 * l + 1];
+            }
+            ++n_it;
+        }
+#endif
+    }
+#ifdef HM_TRUNK_STAMP
+    if (st_on && (threadIdx.x & 63) == 0) {
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_trunk_stamp[threadIdx.x >> 6][i], acc_t[i]);
+        atomicAdd(&g_trunk_stamp[threadIdx.x >> 6][16], n_it);
+    }
+#endif
+#undef TS
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -449,6 +777,20 @@ void launch_trunk(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, i
     const dim3 g(min(n_tiles * n_views, grid)), b(512);
 #define HM_TRUNK(K1, W16) \
     hipLaunchKernelGGL((trunk_kernel<K1, W16>), g, b, 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, sctx, w, maps)
+    if (k1 == 11) { if (w16) HM_TRUNK(11, true); else HM_TRUNK(11, false); }
+    else { if (w16) HM_TRUNK(13, true); else HM_TRUNK(13, false); }
+#undef HM_TRUNK
+}
+
+void launch_trunk2(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
+                   const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,
+                   const TrunkMaps& maps, int grid, bool w16) {
+    if (n_tiles <= 0) return;
+    const dim3 g(min(n_tiles * n_views, grid)), b(256);
+    if (k1 == 11) hipLaunchKernelGGL(rowlist_kernel<11>, dim3(n_tiles * n_views), dim3(128), 0, st, tiles, n_tiles, ctx, rinfo, bases, sctx, maps.rowlist);
+    else hipLaunchKernelGGL(rowlist_kernel<13>, dim3(n_tiles * n_views), dim3(128), 0, st, tiles, n_tiles, ctx, rinfo, bases, sctx, maps.rowlist);
+#define HM_TRUNK(K1, W16) \
+    hipLaunchKernelGGL((trunk2_kernel<K1, W16>), g, b, 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, sctx, w, maps)
     if (k1 == 11) { if (w16) HM_TRUNK(11, true); else HM_TRUNK(11, false); }
     else { if (w16) HM_TRUNK(13, true); else HM_TRUNK(13, false); }
 #undef HM_TRUNK

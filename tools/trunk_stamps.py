@@ -1,0 +1,40 @@
+"""Diagnostic: where a trunk_kernel tile's cycles go.  Needs the stamped build (make -C hifimeth_amd/csrc stamp) and
+HM_LIB_PATH=hifimeth_amd/libhifimeth_hip_stamp.so.  Prints, per layer, the mean shader-clock cycles per tile that
+workgroup 0's waves spend in: prologue (barrier -> first loads issued), k-loop, epilogue, waiting at the next barrier."""
+import ctypes as C
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from hifimeth_amd import MethylationCaller, _lib  # noqa: E402
+from hifimeth_amd.synth import synth_reads  # noqa: E402
+
+reads = synth_reads(400, seed=5)
+mc = MethylationCaller(device=0, timing=True)
+mc.set_option("trunk", 1)
+mc.submit_all(reads)
+mc.upload()
+mc.run()
+mc.sync()
+L = _lib.load() if hasattr(_lib, "load") else C.CDLL(_lib.LIB_PATH)
+fn = C.CDLL(_lib.LIB_PATH).hm_debug_trunk_stamps
+fn.argtypes = [C.c_void_p, C.c_int]
+buf = np.zeros((8, 24), np.uint64)
+fn(None, 1)
+for _ in range(3):
+    mc.run()
+mc.sync()
+assert fn(buf.ctypes.data, 0) == 0
+n = float(buf[0, 16])
+print("tiles of workgroup 0:", int(n), " sites", mc.num_sites(3))
+names = ["prologue", "k-loop", "epilogue", "barrier"]
+tot = np.zeros(8)
+for l in range(4):
+    for ph in range(4):
+        v = buf[:, 4 * l + ph].astype(float) / n
+        tot += v
+        print(f"conv{l + 1} {names[ph]:9s} " + " ".join(f"{x:7.0f}" for x in v))
+print("sum            " + " ".join(f"{x:7.0f}" for x in tot))
+tm = mc.timing()
+print("trunk_ms", tm["trunk_ms"], "positions", tm["trunk_positions"])
