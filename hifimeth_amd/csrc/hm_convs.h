@@ -118,10 +118,21 @@ struct SConv {
                 if (C::XLO) x[c % XS][i][1] = *reinterpret_cast<const half8*>(in_lo + off + (tile0(g) + i) * 16 * C::IRS);
             }
         };
+#ifdef TRK2_STAMP_L1
+        unsigned long long st_[4];
+        constexpr bool ST_ = C::KSTACK > 0;
+        if (ST_) st_[0] = hm_stamp();
+#endif
         static_for<0, (C::XD < NB ? C::XD : NB)>(reads);
+#ifdef TRK2_STAMP_L1
+        if (ST_) st_[1] = hm_stamp();
+#endif
 
         static_for<0, NB>([&](auto c_) __attribute__((always_inline)) {
             constexpr int c = decltype(c_)::value, g = c / KB, kb = c % KB, G = gs[g];
+#ifdef TRK2_STAMP_L1
+            if constexpr (kb == 0 && g > 0 && g < 3) { if (ST_) { unsigned long long t_ = hm_stamp(); if (blockIdx.x == 0 && lane == 0) atomicAdd(&g_trunk_stamp[tid >> 6][19 + g], t_ - st_[1]); } }
+#endif
             if constexpr (kb == 0) {
 #pragma unroll
                 for (int i = 0; i < G; ++i)
@@ -162,10 +173,29 @@ struct SConv {
             if constexpr (c >= 1 && c < CS + 1)
                 cdat[(c - 1) & 1] = *reinterpret_cast<const half8*>(((lane & 16) ? in_lo : in_hi) + crow[(c - 1) % 3] * C::IRS + (lane & 15) * 8);
             if constexpr (c < CS) crow[c % 3] = cpr[c * 2 * Copy::NWV];
-            if constexpr (!std::is_void_v<CN> && g == NG - 1) {
+            if constexpr (!std::is_void_v<CN>) {
+                // the next layer's weights: a register is refilled as soon as its last MFMA of this layer has issued (last
+                // group, k-block kb); registers this layer does not use at all (other k-blocks, the lo plane of a layer with
+                // exact operands) are filled from the first group on -- spread out, because 4 waves x 48 KB through the
+                // CU's 64 B/clk vector-memory path take 3 000 cycles whatever the latency
                 using CNN = std::conditional_t<std::is_void_v<CN>, C, CN>;
-                if constexpr (kb < CNN::KB) sconv_load_w<CNN, kb, kb + 1>(wnext, nt0n, lane, W);
-                if constexpr (kb == KB - 1 && KB < CNN::KB) sconv_load_w<CNN, KB, CNN::KB>(wnext, nt0n, lane, W);
+                constexpr int NPN = CNN::WLO ? 2 : 1, EN = CNN::KB * CNN::NTW * NPN;
+                auto is_free = [](int e) constexpr {
+                    const int kb2 = e / (CNN::NTW * NPN), j2 = e / NPN % CNN::NTW, p2 = e % NPN;
+                    return kb2 >= KB || j2 >= NTW || p2 >= (C::WLO ? 2 : 1);
+                };
+                constexpr int NFREE = [&]() constexpr { int n = 0; for (int e = 0; e < EN; ++e) n += is_free(e); return n; }();
+                constexpr int NEARLY = NB - KB;  // blocks before the last group
+                const half8* wp = reinterpret_cast<const half8*>(wnext) + (size_t)nt0n * CNN::KB * CNN::WSTR + lane;
+                static_for<0, EN>([&](auto e_) __attribute__((always_inline)) {
+                    constexpr int e = decltype(e_)::value;
+                    constexpr int kb2 = e / (CNN::NTW * NPN), j2 = e / NPN % CNN::NTW, p2 = e % NPN;
+                    constexpr bool fr = is_free(e);
+                    constexpr int rank = [&]() constexpr { int n = 0; for (int q = 0; q < e; ++q) n += is_free(q); return n; }();
+                    constexpr bool now = fr ? (NEARLY > 0 ? (c < NEARLY && rank * NEARLY / (NFREE > 0 ? NFREE : 1) == c) : (c == NB - KB))
+                                            : (g == NG - 1 && kb2 == kb);
+                    if constexpr (now) W.w[kb2][j2][p2] = wp[(size_t)(j2 * CNN::KB + kb2) * CNN::WSTR + 64 * p2];
+                });
             }
 #ifndef TRK2_NOSCHED
             {   // the block's LDS reads ride between its first MFMAs, the previous group's epilogue between the others
@@ -190,12 +220,25 @@ struct SConv {
 #endif
             __builtin_amdgcn_sched_barrier(0);
         });
+#ifdef TRK2_STAMP_L1
+        if (ST_) st_[2] = hm_stamp();
+#endif
         {
             constexpr int g = NG - 1;
 #pragma unroll
             for (int a = 0; a < gs[g] * NTW; ++a)
                 epi((tile0(g) + a / NTW) * 16 + li, (nt0 + a % NTW) * 16 + 4 * lk, acc[g & 1][a / NTW][a % NTW]);
         }
+#ifdef TRK2_STAMP_L1
+        if (ST_ && blockIdx.x == 0) {
+            st_[3] = hm_stamp();
+            if (lane == 0) {
+                atomicAdd(&g_trunk_stamp[tid >> 6][17], st_[1] - st_[0]);
+                atomicAdd(&g_trunk_stamp[tid >> 6][18], st_[2] - st_[1]);
+                atomicAdd(&g_trunk_stamp[tid >> 6][19], st_[3] - st_[2]);
+            }
+        }
+#endif
     }
 };
 

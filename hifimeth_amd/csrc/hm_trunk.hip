@@ -19,10 +19,17 @@
 //
 // Reference for what is computed: training/model_cnn.py:8-85 / models/*.onnx (mod_main.cpp:32-98).
 #include "hm_convh.h"
-#include "hm_convs.h"
 #ifdef HM_TRUNK_STAMP  // diagnostic build (make stamp): per-wave shader-clock phase sums of workgroup 0, read by tools/trunk_stamps.py
 #include "hm_stamp.h"
-namespace hm { __device__ unsigned long long g_trunk_stamp[8][24]; }
+namespace hm { __device__ unsigned long long g_trunk_stamp[8][24]; __device__ unsigned long long g_edge_stamp[8][12]; }
+extern "C" int hm_debug_edge_stamps(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(hm::g_edge_stamp), sizeof(hm::g_edge_stamp)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[8][12];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(hm::g_edge_stamp), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 extern "C" int hm_debug_trunk_stamps(unsigned long long* out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(hm::g_trunk_stamp), sizeof(hm::g_trunk_stamp)) != hipSuccess) return -1;
     if (reset) {
@@ -32,6 +39,7 @@ extern "C" int hm_debug_trunk_stamps(unsigned long long* out, int reset) {
     return 0;
 }
 #endif
+#include "hm_convs.h"
 
 namespace hm {
 
@@ -322,18 +330,30 @@ struct EpiE4S {
     __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
         half4 h, l;
         split4(acc, h, l);
+#ifdef TRK2_NOE4
+        asm volatile("" ::"v"(h), "v"(l));
+        return;
+#endif
         *reinterpret_cast<half4*>(g + (size_t)m * (2 * C4_CH) + col) = h;
         *reinterpret_cast<half4*>(g + (size_t)m * (2 * C4_CH) + C4_CH + col) = l;
     }
 };
 
 struct CopyRows3 {  // the same rows over three waves
+#ifdef TRK2_NOCOPY
+    static constexpr int CS = 0, NWV = 3;
+#else
     static constexpr int CS = (TR_OWN / 2 + 2) / 3, NWV = 3;
+#endif
     const uint8_t* rows;
     half_t* g;
 };
 struct CopyRows {
+#ifdef TRK2_NOCOPY
+    static constexpr int CS = 0, NWV = 4;
+#else
     static constexpr int CS = TR_CS, NWV = 4;
+#endif
     const uint8_t* rows;  // LDS: this layer's list of TR_OWN row numbers
     half_t* g;            // map row of tile row 0
 };
@@ -416,7 +436,10 @@ void trunk2_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
 #ifndef TRK2_XD
 #define TRK2_XD 1
 #endif
-    using C1 = SCfg<8, (2 * K1 + 3) / 4 * 4, TR_WRS, 1, true, false, K1, 3>;
+#ifndef TRK2_XD1
+#define TRK2_XD1 2
+#endif
+    using C1 = SCfg<8, (2 * K1 + 3) / 4 * 4, TR_WRS, 1, true, false, K1, TRK2_XD1>;
     using C2 = SCfg<128, 3, TR_RS, 2, !W16, true, 0, TRK2_XD>;
     using C3 = SCfg<128, 3, TR_RS, 4, !W16, true, 0, TRK2_XD>;
 #ifndef TRK2_C4W4  // conv4 on three waves, two channel tiles each, all positions (three tiles x half the positions on four
@@ -432,7 +455,7 @@ void trunk2_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     const int nt04 = 3 * (wave & 1);
 #endif
     using L1 = SConv<C1, C2, 0, 3, 3, 3>;
-    using L2 = SConv<C2, C3, 0, 3, 3, 3>;
+    using L2 = SConv<C2, C3, 0, 2, 3, 4>;  // the longest group last: it is the window in which conv3's weights can be fetched
     using L3 = SConv<C3, C4, 0, 4, 4>;
     static_assert(TR_M1 == 144 && TR_M2 == 144 && TR_M3 == 128 && TR_M4 == 112, "tile groups of the streaming layers");
     static_assert(TR_XROWS <= NW * 64, "one feature row per thread");
@@ -629,40 +652,63 @@ __global__ __launch_bounds__(512) void edge_kernel(SiteRange sr, const RInfo* __
     // Site descriptors + feature rows of the pass that starts at site s0, by threads [0, nt) (t < 0: not taking part).
     // A dependent chain of loads (site -> read -> base) followed by 1024 row builds: done for the NEXT pass by the two
     // waves that have no tile in the last layer (96 channels = 6 waves), so that a pass starts with everything in LDS.
-    auto prepare = [&](const int s0, EdgeSite* si, const int t, const int nt) __attribute__((always_inline)) {
-        const int nvalid = min(EG_S, n_sites - s0);
-        if (t >= 0 && t < EG_S) {
-            const int i = min(t, nvalid - 1);  // pad slots repeat the last site; their results are dropped
-            const Site st = sites[s0 + i];
-            const RInfo ri = rinfo[st.read_idx];
+    // The descriptors are a chain of three dependent loads (site -> read -> base at the site).  For the NEXT pass every
+    // thread walks it for site (t mod 32), one link per layer of the current pass, so that each link's latency has a whole
+    // layer to hide behind; all threads issue the same few loads unconditionally -- a load behind a branch would make the
+    // compiler's wait counts for everything after it conservative.
+    struct Desc {
+        Site st;
+        RInfo ri;
+        int bs, valid;
+    } nd;
+    auto desc_a = [&](const int s0) __attribute__((always_inline)) {
+        const int sc = min(s0, max(n_sites - 1, 0));                      // past the end: the last pass's sites again, dropped below
+        const int nvalid = s0 < n_sites ? min(EG_S, n_sites - s0) : 0;
+        const int t = threadIdx.x & (EG_S - 1);
+        nd.valid = t < nvalid;
+        nd.st = sites[min(sc + t, max(n_sites - 1, 0))];  // pad slots repeat the last site; their results are dropped
+    };
+    auto desc_b = [&]() __attribute__((always_inline)) { nd.ri = rinfo[nd.st.read_idx]; };
+    auto desc_c = [&]() __attribute__((always_inline)) { nd.bs = bases[nd.ri.base_off + nd.st.qoff]; };
+    auto desc_d = [&](const int s0, EdgeSite* si) __attribute__((always_inline)) {
+        if ((int)threadIdx.x < EG_S) {
             EdgeSite es;
-            es.bo = ri.base_off;
-            es.L = ri.len;
-            es.view = bases[ri.base_off + st.qoff] == 2;
-            es.off = es.view ? ri.len - 1 - st.qoff : st.qoff;
-            es.vrow = (int64_t)es.view * mp.view_rows + ri.map_off + TR_PAD;
-            es.valid = t < nvalid;
-            si[t] = es;
-            if (es.valid) e4row[s0 + t] = (int32_t)(es.vrow + es.off - 215);
+            es.bo = nd.ri.base_off;
+            es.L = nd.ri.len;
+            es.view = nd.bs == 2;
+            es.off = es.view ? nd.ri.len - 1 - nd.st.qoff : nd.st.qoff;
+            es.vrow = (int64_t)es.view * mp.view_rows + nd.ri.map_off + TR_PAD;
+            es.valid = nd.valid;
+            si[threadIdx.x] = es;
+            if (es.valid) e4row[s0 + threadIdx.x] = (int32_t)(es.vrow + es.off - 215);
         }
     };
-    // feature rows of conv1's first / last output: K1 rows per pseudo-row, the one on the zero padding all zeros
-    auto build_rows = [&](const EdgeSite* si, const int t, const int nt) __attribute__((always_inline)) {
-        for (int i = t; i < EG_M * EG_XROWS; i += nt) {
+    // feature rows of conv1's first / last output: K1 rows per pseudo-row, the one on the zero padding all zeros.
+    // NR rows per thread, all their loads issued before the first is used (clamped addresses, no branches).
+    auto build_rows = [&](const EdgeSite* si, const int t, auto nt_) __attribute__((always_inline)) {
+        constexpr int NT = decltype(nt_)::value, NR = EG_M * EG_XROWS / NT;
+        int b[NR];
+        uint32_t k[NR];
+        bool live[NR];
+        int view[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int i = t + u * NT;
             const int r = i / EG_XROWS, tt = i - r * EG_XROWS;
             const int side = r >= EG_S, site = r - side * EG_S;
             const EdgeSite& es = si[site];
             const int x = es.off + (side ? G::X_RIGHT : G::X_LEFT) + tt;
             const bool is_pad = side ? tt == K1 - 1 : tt == 0;
-            int b = -1;
-            uint32_t k = 0;
-            if (tt < K1 && !is_pad && x >= 0 && x < es.L) {
-                const int64_t j = es.bo + (es.view ? es.L - 1 - x : x);
-                b = bases[j];
-                k = kin[j];
-            }
-            *reinterpret_cast<uint4*>(xb + i * TR_WRS) = feature_row(b, k, es.view);
+            live[u] = tt < K1 && !is_pad && x >= 0 && x < es.L;
+            view[u] = es.view;
+            const int xc = min(max(x, 0), es.L - 1);
+            const int64_t j = es.bo + (es.view ? es.L - 1 - xc : xc);
+            b[u] = bases[j];
+            k[u] = kin[j];
         }
+#pragma unroll
+        for (int u = 0; u < NR; ++u)
+            *reinterpret_cast<uint4*>(xb + (t + u * NT) * TR_WRS) = feature_row(live[u] ? b[u] : -1, k[u], view[u]);
     };
 
     // Shared (map) rows of layer `LAYER` (2..4) of all pseudo-rows: left chains read one row, right chains one or two.
@@ -713,15 +759,25 @@ __global__ __launch_bounds__(512) void edge_kernel(SiteRange sr, const RInfo* __
             else v = m4[j];
             *reinterpret_cast<uint4*>((plane ? op_lo : op_hi) + (r * 3 + tap) * TR_RS + q * 8) = v;
         }
-        constexpr int CHUNKS = EG_M * 3 * 2 * 16;  // 16-byte chunks: pseudo-row x tap x plane x 16
-        for (int i = threadIdx.x; i < CHUNKS; i += NW * 64) {
-            const int q = i & 15, plane = (i >> 4) & 1, rt = i >> 5;
-            const int r = rt / 3, tap = rt - 3 * r;
-            const TapSrc src = tap_source<K1>(LAYER, r >= EG_S, tap);
-            if (src.kind == SRC_MAP) continue;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (src.kind == SRC_SPEC) v = *reinterpret_cast<const uint4*>((plane ? sp_lo : sp_hi) + r * TR_RS + q * 8);
-            *reinterpret_cast<uint4*>((plane ? op_lo : op_hi) + (r * 3 + tap) * TR_RS + q * 8) = v;
+        // the previous layer's edge outputs ("specific" tap) and the zero tap, side by side: per side the tap of each kind is
+        // a compile-time constant, so the two copies are plain strided loops (pseudo-row x plane x 16 sixteen-byte chunks)
+        constexpr int HALF = EG_S * 2 * 16;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            int spec_tap = -1, zero_tap = -1;
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const TapSrc src = tap_source<K1>(LAYER, side, tap);
+                if (src.kind == SRC_SPEC) spec_tap = tap;
+                if (src.kind == SRC_ZERO) zero_tap = tap;
+            }
+            for (int i = threadIdx.x; i < HALF; i += NW * 64) {
+                const int q = i & 15, plane = (i >> 4) & 1, r = side * EG_S + (i >> 5);
+                const uint4 v = *reinterpret_cast<const uint4*>((plane ? sp_lo : sp_hi) + r * TR_RS + q * 8);
+                half_t* o = (plane ? op_lo : op_hi) + (r * 3) * TR_RS + q * 8;
+                *reinterpret_cast<uint4*>(o + spec_tap * TR_RS) = v;
+                if (zero_tap >= 0) *reinterpret_cast<uint4*>(o + zero_tap * TR_RS) = make_uint4(0u, 0u, 0u, 0u);
+            }
         }
     };
     using L2t = std::integral_constant<int, 2>;
@@ -729,44 +785,77 @@ __global__ __launch_bounds__(512) void edge_kernel(SiteRange sr, const RInfo* __
     using L4t = std::integral_constant<int, 4>;
 
     if ((int)blockIdx.x * EG_S < n_sites) {  // first pass of this workgroup: prepared by everybody
-        prepare(blockIdx.x * EG_S, sinfo2[0], threadIdx.x, NW * 64);
+        desc_a(blockIdx.x * EG_S);
+        desc_b();
+        desc_c();
+        desc_d(blockIdx.x * EG_S, sinfo2[0]);
         __syncthreads();
-        build_rows(sinfo2[0], threadIdx.x, NW * 64);
+        build_rows(sinfo2[0], threadIdx.x, std::integral_constant<int, NW * 64>{});
     }
     int cur = 0;
+#ifdef HM_TRUNK_STAMP
+    unsigned long long ets[12], eacc[12] = {};
+    unsigned long long en_it = 0;
+    const bool est_on = blockIdx.x == 0;
+#define ETS(i) do { if (est_on) ets[i] = hm_stamp(); } while (0)
+#else
+#define ETS(i)
+#endif
     for (int s0 = blockIdx.x * EG_S; s0 < n_sites; s0 += gridDim.x * EG_S) {
         const int nvalid = min(EG_S, n_sites - s0);
         sinfo = sinfo2[cur];
         __syncthreads();  // descriptors + feature rows of this pass are in LDS; the previous pass is done with the planes
+        ETS(0);
+        const int sn = s0 + gridDim.x * EG_S;
+        desc_a(sn);
         request(L2t{});
         C1E::run(xb, xb, reinterpret_cast<const half_t*>(W.c1f), EpiSpecC1{sp_hi, sp_lo, W.c1f_bias, W.c1f_corr});
-        // requested behind conv1's own (weight) loads: a wave's loads return in order, so in front of them these rows would
-        // have to arrive before conv1 could start
+        // (conv1 first, the layer-2 rows requested behind its loads, was tried: this phase 12.7 k -> 14.4 k cycles)
         request(L3t{});
         request(L4t{});
+        ETS(1);
         __syncthreads();
+        ETS(2);
         stage(L2t{});
         __syncthreads();
+        ETS(3);
+        desc_b();
         CE128::run(op_hi, op_lo, wf(1), EpiSpec{sp_hi, sp_lo, W.bias[1]});
+        ETS(4);
         __syncthreads();
+        ETS(5);
         stage(L3t{});
         __syncthreads();
+        ETS(6);
+        desc_c();
         CE128::run(op_hi, op_lo, wf(2), EpiSpec{sp_hi, sp_lo, W.bias[2]});
         __syncthreads();
+        ETS(7);
+        desc_d(sn, sinfo2[cur ^ 1]);
         stage(L4t{});
         __syncthreads();
-        const int sn = s0 + gridDim.x * EG_S;
-        if ((int)threadIdx.x >= 384) {  // waves 6, 7 have no tile in the 96-channel layer: they prepare the next pass
-            if (sn < n_sites && (int)threadIdx.x < 448) {  // one wave: its descriptors are visible to itself without a barrier
-                prepare(sn, sinfo2[cur ^ 1], threadIdx.x - 384, 64);
-                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the descriptors are in LDS before this wave reads them back
-                build_rows(sinfo2[cur ^ 1], threadIdx.x - 384, 64);
-            }
+        ETS(8);
+        if ((int)threadIdx.x >= 384) {  // waves 6, 7 have no tile in the 96-channel layer: they build the next pass's feature rows
+            build_rows(sinfo2[cur ^ 1], threadIdx.x - 384, std::integral_constant<int, 128>{});
         } else {
             CE96::run(op_hi, op_lo, wf(3), EpiEdgeOut{reinterpret_cast<half_t*>(edge4) + (size_t)s0 * (4 * C4_CH), W.bias[3], nvalid});
         }
+        ETS(9);
         cur ^= 1;
+#ifdef HM_TRUNK_STAMP
+        if (est_on) {
+            for (int i = 0; i < 9; ++i) eacc[i] += ets[i + 1] - ets[i];
+            ++en_it;
+        }
+#endif
     }
+#ifdef HM_TRUNK_STAMP
+    if (est_on && (threadIdx.x & 63) == 0) {
+        for (int i = 0; i < 9; ++i) atomicAdd(&g_edge_stamp[threadIdx.x >> 6][i], eacc[i]);
+        atomicAdd(&g_edge_stamp[threadIdx.x >> 6][9], en_it);
+    }
+#endif
+#undef ETS
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

@@ -21,6 +21,9 @@ L = _lib.load() if hasattr(_lib, "load") else C.CDLL(_lib.LIB_PATH)
 fn = C.CDLL(_lib.LIB_PATH).hm_debug_trunk_stamps
 fn.argtypes = [C.c_void_p, C.c_int]
 buf = np.zeros((8, 24), np.uint64)
+fe = C.CDLL(_lib.LIB_PATH).hm_debug_edge_stamps
+fe.argtypes = [C.c_void_p, C.c_int]
+fe(None, 1)
 fn(None, 1)
 for _ in range(3):
     mc.run()
@@ -35,6 +38,15 @@ for l in range(4):
         v = buf[:, 4 * l + ph].astype(float) / n
         tot += v
         print(f"conv{l + 1} {names[ph]:9s} " + " ".join(f"{x:7.0f}" for x in v))
+print("L1 parts [prologue reads, stream, final epilogue]:", (buf[:4, 17:20].astype(float) / n).round(0).tolist(), 'group starts', (buf[:4, 20:22].astype(float) / n).round(0).tolist())
 print("sum            " + " ".join(f"{x:7.0f}" for x in tot))
 tm = mc.timing()
 print("trunk_ms", tm["trunk_ms"], "positions", tm["trunk_positions"])
+
+eb = np.zeros((8, 12), np.uint64)
+assert fe(eb.ctypes.data, 0) == 0
+ne = float(eb[0, 9])
+print("edge passes of workgroup 0:", int(ne))
+for i, nm in enumerate(["req2+conv1+req34", "barrier", "stage2+bar", "conv2", "barrier", "stage3+bar", "conv3+bar", "stage4+bar", "conv4|prepare"]):
+    print(f"edge {nm:18s} " + " ".join(f"{x:7.0f}" for x in eb[:, i].astype(float) / ne))
+print("edge sum           " + " ".join(f"{x:7.0f}" for x in eb[:, :9].astype(float).sum(1) / ne))
