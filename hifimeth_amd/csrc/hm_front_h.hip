@@ -16,8 +16,27 @@
 // Reference for what is computed: training/model_cnn.py:8-85 / models/*.onnx (mod_main.cpp:32-98).
 #include "hm_convh.h"
 #include "hm_stamp.h"
+#ifdef HM_TRUNK_STAMP
+namespace hm { __device__ unsigned long long g_tail_stamp[8][16]; }
+extern "C" int hm_debug_tail_stamps(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(hm::g_tail_stamp), sizeof(hm::g_tail_stamp)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[8][16];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(hm::g_tail_stamp), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 namespace hm {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_h(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_h<I + 1, N>(f);
+    }
+}
 
 // ReLU + split; 4 consecutive channels of position m -> the hi and lo planes (physical row m+1)
 template <int ORS>
@@ -440,7 +459,6 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
     constexpr int SPLIT_SITE = 3;  // S * C6_SS (conv6's output in buffer 0) ends inside site 2's input rows
     static_assert(S * T::C6_SS <= SPLIT_SITE * T::IN_SS, "conv6's output must not reach the sites staged during conv7");
     constexpr int NHI = ((S - SPLIT_SITE) * Q4 + 127) / 128, NLO = (SPLIT_SITE * Q4 + 127) / 128;
-    __shared__ int32_t s_row[2][S];  // GATHER: E4 map row (position off - 215) of the sites of the next group
     auto load_row = [&](int grp, int t) __attribute__((always_inline)) {
         int32_t r = 0;
         if (GATHER && t < S && grp * S + t < n_sites) r = e4row[grp * S + t];
@@ -460,31 +478,54 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
     // pieces below LOW_PIECES overlap conv6's output in buffer 0 and may only be written once conv7 has read it
     constexpr int LOW_PIECES = (S * T::C6_SS * 2 + 1023) / 1024;
     const int lane = threadIdx.x & 63;
-    auto stage_piece = [&](const int grp, const int p, const int pl, const int rs) __attribute__((always_inline)) {
-        const int u = 64 * p + lane;
-        if (u < UNITS) {
-            const int R = u / 13, ch = u - 13 * R;
-            const int site = R / (T::L4 + 2), prow = R - (T::L4 + 2) * site;
-            const int gs = grp * S + site, pos = prow - 1;
-            const half_t* src = zeros;
-            if (pos >= 0 && pos < C4_LEN && ch < 12 && gs < n_sites) {
-                src = (pos == 0            ? edge4 + (size_t)gs * (4 * C4_CH)
-                       : pos == C4_LEN - 1 ? edge4 + (size_t)gs * (4 * C4_CH) + 2 * C4_CH
-                                           : e4 + ((size_t)s_row[rs][site] + 16 * pos) * (2 * C4_CH)) +
-                      pl * C4_CH + ch * 8;
+    // Pieces [P_LO, P_HI) of plane PL, dealt round-robin to the NWV waves starting at wave W0.  The loop over a wave's
+    // pieces is unrolled, so a lane's unit 64 p + lane = U0 (compile time) + t with t = 64 (wave - W0) + lane fixed for the
+    // whole kernel: row, channel chunk, site and window position follow from t / 13 and t % 13 (computed once) with two
+    // carries instead of two integer divisions per piece, the site's map row comes out of `rows` (lane l holds the row of
+    // site l & 7) by readlane, and the source is selected without branches -- the spare waves' address arithmetic, not the
+    // DMA, set the length of the conv6 / conv8 phases (measured: 680 cycles per piece).
+    auto stage_set = [&](auto pl_, auto plo_, auto phi_, auto w0_, auto nwv_, const int grp, const int32_t rows) __attribute__((always_inline)) {
+        constexpr int PL = decltype(pl_)::value, P_LO = decltype(plo_)::value, P_HI = decltype(phi_)::value;
+        constexpr int W0 = decltype(w0_)::value, NWV = decltype(nwv_)::value;
+        constexpr int K = (P_HI - P_LO + NWV - 1) / NWV;
+        const int wo = wave_id() - W0;
+        const int t = 64 * wo + lane, tq = t / 13, t13 = t - 13 * tq;
+        const uint32_t plane0 = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) half_t*)(PL ? l0 : h0));
+        const half_t* e4p = e4 + PL * C4_CH;
+        const half_t* edp = edge4 + PL * C4_CH;
+        static_for_h<0, K>([&](auto k_) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_)::value;
+            constexpr int U0 = 64 * (P_LO + k * NWV), AQ = U0 / 13, AR = U0 % 13, BQ = AQ / (T::L4 + 2), BR_ = AQ % (T::L4 + 2);
+            if ((P_LO + (k + 1) * NWV <= P_HI) || P_LO + k * NWV + wo < P_HI) {
+                const int s1 = AR + t13, c1 = s1 >= 13, ch = s1 - 13 * c1;
+                const int s2 = BR_ + tq + c1, c2 = (s2 >= T::L4 + 2) + (s2 >= 2 * (T::L4 + 2)), prow = s2 - (T::L4 + 2) * c2;
+                static_assert((T::L4 + 1) + (64 * NWV - 1) / 13 + 1 < 3 * (T::L4 + 2), "at most two row-to-site carries");
+                const int site = BQ + c2, pos = prow - 1, gs = grp * S + site;
+                const int32_t ra = __builtin_amdgcn_readlane(rows, BQ < S ? BQ : S - 1), rb = __builtin_amdgcn_readlane(rows, BQ + 1 < S ? BQ + 1 : S - 1);
+                const int32_t rc = __builtin_amdgcn_readlane(rows, BQ + 2 < S ? BQ + 2 : S - 1);
+                const int64_t mrow = (int64_t)(c2 == 0 ? ra : c2 == 1 ? rb : rc) + 16 * pos;
+                const bool data = pos >= 0 && pos < C4_LEN && ch < 12 && gs < n_sites && site < S;
+                const bool edge = pos == 0 || pos == C4_LEN - 1;
+                const half_t* sm = e4p + mrow * (2 * C4_CH) + ch * 8;
+                const half_t* se = edp + (int64_t)gs * (4 * C4_CH) + (pos ? 2 * C4_CH : 0) + ch * 8;
+                const half_t* src = data ? (edge ? se : sm) : zeros;
+                const uint32_t dst = plane0 + 1024u * (uint32_t)(P_LO + k * NWV + wo);
+                uint32_t keep;
+                if (U0 + 64 * NWV <= UNITS || U0 + t < UNITS)
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
             }
-            // M0 = LDS byte address of the piece; the compiler reserves M0, so it is saved and restored around the DMA
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(
-                (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) half_t*)(pl ? l0 : h0) + 1024u * (uint32_t)p);
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-        }
+        });
     };
-    // pieces [p_lo, p_hi) of plane pl, dealt round-robin to the `nw` waves starting at wave w0
-    auto stage_range = [&](int grp, int pl, int p_lo, int p_hi, int w0, int nw, int rs) __attribute__((always_inline)) {
-        for (int p = p_lo + (wave_id() - w0); p < p_hi; p += nw) stage_piece(grp, p, pl, rs);
-    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
+    using I6 = std::integral_constant<int, 6>;
+    using I8 = std::integral_constant<int, 8>;
+    using ILOW = std::integral_constant<int, LOW_PIECES>;
+    using IPCS = std::integral_constant<int, PIECES>;
     auto put_elem = [&](int i, const float4& v) __attribute__((always_inline)) {  // fp32 -> split planes 0, rows 1..25
         const int site = i / Q4, rem = (i - site * Q4) * 4;
         const int pos = rem / C4_CH, c = rem - pos * C4_CH;
@@ -508,20 +549,20 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
     // other paths the registers would count as live around the whole loop -- across conv5 -- and spill.
     auto fake_def = [](float4& v) __attribute__((always_inline)) { asm volatile("" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)); };
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int32_t pend = 0;
+    int32_t pend = 0, rows = 0;  // GATHER: lane l of a staging wave holds the E4 map row (position off - 215) of site l & 7 of the
+                                 // group it stages next (rows) / of the group after that (pend, requested a pass ahead)
     int it = 0;
     float4 phi[NHI], plo[NLO];
 
     // first group of this workgroup: staged by everybody
     if constexpr (GATHER) {
-        if ((int)threadIdx.x < S) s_row[0][threadIdx.x] = load_row(g_begin, threadIdx.x);
-        __syncthreads();
-        if (wave == 7) pend = load_row(g_begin + 1, threadIdx.x - 448);
+        rows = load_row(g_begin, lane & (S - 1));
+        if (wave >= 4) pend = load_row(g_begin + 1, lane & (S - 1));
     }
     if (g_begin < g_end) {
         if constexpr (GATHER) {
-            stage_range(g_begin, 0, 0, PIECES, 0, NW, 0);
-            stage_range(g_begin, 1, 0, PIECES, 0, NW, 0);
+            stage_set(I0{}, I0{}, IPCS{}, I0{}, I8{}, g_begin, rows);
+            stage_set(I1{}, I0{}, IPCS{}, I0{}, I8{}, g_begin, rows);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA is invisible to the compiler's own wait counting
         } else {
             for (int i = threadIdx.x; i < S * Q4; i += NW * 64) {
@@ -532,18 +573,29 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         }
     }
     int slot = 0, g_first = g_begin;  // groups g_first, g_first + 1, ... wait in ring slots 0 .. slot-1
+#ifdef HM_TRUNK_STAMP
+    unsigned long long tts[12], tacc[12] = {};
+    unsigned long long tn = 0;
+    const bool tst = blockIdx.x == 0 && GATHER;
+#define TTS(i) do { if (tst) tts[i] = hm_stamp(); } while (0)
+#else
+#define TTS(i)
+#endif
     for (int g = g_begin; g < g_end; ++g) {
         const bool more = g + 1 < g_end;
         if constexpr (GATHER) {  // map rows of group g + grid (requested one iteration ago) -> LDS
             ++it;
-            if (wave == 7 && (int)threadIdx.x - 448 < S) s_row[it & 1][threadIdx.x - 448] = pend;
+            rows = pend;
         }
-        __syncthreads();  // input of group g staged (by the previous iteration's spare waves); s_row visible
+        __syncthreads();  // input of group g staged (by the previous iteration's spare waves)
+        TTS(0);
 
         ConvH<NW, 96, 3, 96, T::L5, T::RS96, 4, 2, 3, S, T::IN_SS, 0, (W16T < 2)>::run(
             h0, l0, wf(4), EpiPlanesS<T::L5, T::RS96, T::C5_SS>{h1, l1, W.bias[4]});
         zero_pad_rows_h<S, T::L5, 96>(h1, l1, T::RS96, T::C5_SS);
+        TTS(1);
         __syncthreads();
+        TTS(2);
         if (dbg && dbg_layer == 5 && g == 0) dump_planes<T::L5, 96, T::RS96>(h1, l1, dbg);
 
         // conv6 / conv7 as 1xN grids (a wave owns one 16-channel tile and every position): with 4x2 / 2x4 grids four
@@ -551,7 +603,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         // (explicit if / else on the wave id, not a call that returns early: the staged rows must not be live across
         //  the other waves' conv code or they spill)
         if (GATHER && wave >= 6) {  // spare in conv6: the hi plane's pieces behind conv6's output, by LDS-DMA
-            if (more) stage_range(g + 1, 0, LOW_PIECES, PIECES, 6, 2, it & 1);
+            if (more) stage_set(I0{}, ILOW{}, IPCS{}, I6{}, I2{}, g + 1, rows);
         } else if (wave >= 6) {  // spare in conv6: request sites 3..7 of the next group
             if (more) {
                 int tl = threadIdx.x;
@@ -574,11 +626,13 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
             for (int k = 0; k < NHI; ++k) fake_def(phi[k]);
         }
         zero_pad_rows_h<S, T::L6, 96>(h0, l0, T::RS96, T::C6_SS);
+        TTS(3);
         __syncthreads();
+        TTS(4);
         if (dbg && dbg_layer == 6 && g == 0) dump_planes<T::L6, 96, T::RS96>(h0, l0, dbg);
 
         if (GATHER && wave >= 4) {  // spare in conv7: the same pieces of the lo plane
-            if (more) stage_range(g + 1, 1, LOW_PIECES, PIECES, 4, 4, it & 1);
+            if (more) stage_set(I1{}, ILOW{}, IPCS{}, I4{}, I4{}, g + 1, rows);
         } else if (wave >= 6) {  // spare in conv7: the requested rows -> buffer 0 (behind conv6's output)
             if (more) {
                 int tl = threadIdx.x;
@@ -613,15 +667,17 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
             for (int k = 0; k < NLO; ++k) fake_def(plo[k]);
         }
         zero_pad_rows_h<S, T::L7, 64>(h1, l1, T::RS64, T::C7_SS);
+        TTS(5);
         __syncthreads();
+        TTS(6);
         if (dbg && dbg_layer == 7 && g == 0) dump_planes<T::L7, 64, T::RS64>(h1, l1, dbg);
 
         if (GATHER && wave >= 4) {  // spare in conv8: the pieces that held conv6's output (dead since the last barrier)
             if (more) {
-                stage_range(g + 1, 0, 0, LOW_PIECES, 4, 4, it & 1);
-                stage_range(g + 1, 1, 0, LOW_PIECES, 4, 4, it & 1);
+                stage_set(I0{}, I0{}, ILOW{}, I4{}, I4{}, g + 1, rows);
+                stage_set(I1{}, I0{}, ILOW{}, I4{}, I4{}, g + 1, rows);
             }
-            if (wave == 7) pend = load_row(g + 2, threadIdx.x - 448);
+            pend = load_row(g + 2, lane & (S - 1));
             // everything this wave staged for the next group is in LDS before it reaches the barrier in front of conv5
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (wave >= 4) {
@@ -639,6 +695,10 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
             ConvH<NW, 64, 3, 64, T::L8, T::RS64, 1, 4, 3, S, T::C7_SS, 0, (W16T < 1)>::run(
                 h1, l1, wf(7), EpiRing<T::L8, T::RS64>{r_hi + slot * S * T::RING_SS, r_lo + slot * S * T::RING_SS, W.bias[7]});
         }
+        TTS(7);
+#ifdef HM_TRUNK_STAMP
+        if (tst) { for (int i = 0; i < 7; ++i) tacc[i] += tts[i + 1] - tts[i]; ++tn; }
+#endif
         if (slot == 0) g_first = g;
         ++slot;
         if (dbg && dbg_layer == 8 && g == 0) {
@@ -650,6 +710,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         }
         if (slot < FCB && more) continue;  // the loop-top barrier orders this conv8 before the next conv5
         __syncthreads();
+        TTS(8);
 
         // fc1 as a 2-tap "conv" over conv8's two positions (k order l*64 + c; see hm_weights.cpp), FCB * S sites at once;
         // slots this batch did not fill hold stale rows whose results are never written out
@@ -687,7 +748,18 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
             }
         }
         slot = 0;  // hfc (buffer 1) and the ring are next written behind the loop-top barrier / the conv7 barrier
+        TTS(9);
+#ifdef HM_TRUNK_STAMP
+        if (tst) { tacc[8] += tts[9] - tts[8]; tacc[9] += 1; }
+#endif
     }
+#ifdef HM_TRUNK_STAMP
+    if (tst && (threadIdx.x & 63) == 0) {
+        for (int i = 0; i < 10; ++i) atomicAdd(&g_tail_stamp[threadIdx.x >> 6][i], tacc[i]);
+        atomicAdd(&g_tail_stamp[threadIdx.x >> 6][10], tn);
+    }
+#endif
+#undef TTS
 }
 
 static int cnn_grid_h(const SiteRange& sr, int per_group, int grid) {

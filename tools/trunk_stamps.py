@@ -24,6 +24,9 @@ buf = np.zeros((8, 24), np.uint64)
 fe = C.CDLL(_lib.LIB_PATH).hm_debug_edge_stamps
 fe.argtypes = [C.c_void_p, C.c_int]
 fe(None, 1)
+ft = C.CDLL(_lib.LIB_PATH).hm_debug_tail_stamps
+ft.argtypes = [C.c_void_p, C.c_int]
+ft(None, 1)
 fn(None, 1)
 for _ in range(3):
     mc.run()
@@ -50,3 +53,12 @@ print("edge passes of workgroup 0:", int(ne))
 for i, nm in enumerate(["req2+conv1+req34", "barrier", "stage2+bar", "conv2", "barrier", "stage3+bar", "conv3+bar", "stage4+bar", "conv4|prepare"]):
     print(f"edge {nm:18s} " + " ".join(f"{x:7.0f}" for x in eb[:, i].astype(float) / ne))
 print("edge sum           " + " ".join(f"{x:7.0f}" for x in eb[:, :9].astype(float).sum(1) / ne))
+
+tb = np.zeros((8, 16), np.uint64)
+assert ft(tb.ctypes.data, 0) == 0
+nt = float(tb[0, 10])
+print("tail passes of workgroup 0:", int(nt), " fc batches", int(tb[0, 9]))
+for i, nm in enumerate(["conv5", "barrier", "conv6|stage", "barrier", "conv7|stage", "barrier", "conv8|stage"]):
+    print(f"tail {nm:14s} " + " ".join(f"{x:7.0f}" for x in tb[:, i].astype(float) / nt))
+print("tail fc1+fc2 per pass " + " ".join(f"{x:7.0f}" for x in tb[:, 8].astype(float) / nt))
+print("tail sum            " + " ".join(f"{x:7.0f}" for x in (tb[:, :7].astype(float).sum(1) + tb[:, 8]) / nt))
