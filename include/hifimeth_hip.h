@@ -91,8 +91,10 @@ const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a fa
  * 1 = split-half fp16x3 MFMA with fp32 accumulate (default); 2 = 1 with plain fp16 WEIGHTS in conv6..conv8, the part of the
  * network where they hold BASELINE.json configs[4]'s bar |dp| <= 1e-3 (tools/w16_error_table.py); 3 = fp16 weights in
  * conv2..conv8, the literal configs[4], which misses that bar (max |dp| ~ 2.5e-3): kept for the record; activations stay
- * split and accumulation fp32 in every mode), "trunk" (1 = conv1..conv4 once per read position, default; 0 = once per
- * site), "group_bases" (reads per trunk group, default 2 Mi bases), "stamps" (diagnostic) */
+ * split and accumulation fp32 in every mode), "trunk" (2 = per context by site density, default; 1 = conv1..conv4 once per
+ * read position; 0 = once per site; every precision has both forms), "trunk_impl" (1 = streaming 4-wave trunk kernel,
+ * default; 0 = the 8-wave form; byte-identical results), "group_bases" (reads per trunk group, default 2 Mi bases),
+ * "stamps" (diagnostic) */
 int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
 
 /* ---- staging: the EvalKmerFeaturesGenerator::init seam ----------------------------------- */

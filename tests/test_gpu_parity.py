@@ -521,3 +521,20 @@ def test_batches_staged_from_several_threads(mc):
     for w, g in zip(want, got):
         assert w.tobytes() == g.tobytes()
     assert len(want[-1]) == 0 and len(want[-2]) == 0
+
+
+def test_streaming_trunk_is_byte_identical_to_the_8_wave_form():
+    """Engine option trunk_impl: the streaming 4-wave trunk kernel (weights resident in registers, positions streamed in
+    tile groups, map rows copied out through row lists) keeps every accumulator's order of products, so its calls are
+    byte-identical to the 8-wave kernel's -- including reads shorter than a tile, homopolymers (every row flagged) and
+    wide kinetics."""
+    from hifimeth_amd import MethylationCaller
+    reads = _mixed_reads() + synth_reads(6, seed=77, median_len=5000, sigma=0.5, frac_wide=0.3)
+    out = []
+    for impl in (0, 1):
+        with MethylationCaller(device=0) as m:
+            m.set_option("trunk", 1)
+            m.set_option("trunk_impl", impl)
+            out.append(m.call(reads).copy())
+    assert len(out[0]) == len(out[1]) > 1000
+    assert out[0].tobytes() == out[1].tobytes()

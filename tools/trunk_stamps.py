@@ -34,14 +34,18 @@ mc.sync()
 assert fn(buf.ctypes.data, 0) == 0
 n = float(buf[0, 16])
 print("tiles of workgroup 0:", int(n), " sites", mc.num_sites(3))
-names = ["prologue", "k-loop", "epilogue", "barrier"]
+streaming = not buf[:, 1].any()  # trunk2_kernel stamps a layer as a whole (slot 0) and the wait at its barrier (slot 3)
+names = ["layer", "", "", "barrier"] if streaming else ["prologue", "k-loop", "epilogue", "barrier"]
+print("shader-clock cycles per tile, one column per wave of workgroup 0" + (" (streaming form: 4 waves)" if streaming else ""))
 tot = np.zeros(8)
 for l in range(4):
     for ph in range(4):
         v = buf[:, 4 * l + ph].astype(float) / n
         tot += v
-        print(f"conv{l + 1} {names[ph]:9s} " + " ".join(f"{x:7.0f}" for x in v))
-print("L1 parts [prologue reads, stream, final epilogue]:", (buf[:4, 17:20].astype(float) / n).round(0).tolist(), 'group starts', (buf[:4, 20:22].astype(float) / n).round(0).tolist())
+        if names[ph]:
+            print(f"conv{l + 1} {names[ph]:9s} " + " ".join(f"{x:7.0f}" for x in v))
+if buf[:, 17:22].any():
+    print("L1 parts [prologue reads, stream, final epilogue]:", (buf[:4, 17:20].astype(float) / n).round(0).tolist(), 'group starts', (buf[:4, 20:22].astype(float) / n).round(0).tolist())
 print("sum            " + " ".join(f"{x:7.0f}" for x in tot))
 tm = mc.timing()
 print("trunk_ms", tm["trunk_ms"], "positions", tm["trunk_positions"])
