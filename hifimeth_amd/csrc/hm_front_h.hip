@@ -590,6 +590,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         __syncthreads();  // input of group g staged (by the previous iteration's spare waves)
         TTS(0);
 
+        // (wave grids 2x3, 1x6, 4x1 and weight prefetch depths 4, 5 measured the same or worse in same-session A/Bs)
         ConvH<NW, 96, 3, 96, T::L5, T::RS96, 4, 2, 3, S, T::IN_SS, 0, (W16T < 2)>::run(
             h0, l0, wf(4), EpiPlanesS<T::L5, T::RS96, T::C5_SS>{h1, l1, W.bias[4]});
         zero_pad_rows_h<S, T::L5, 96>(h1, l1, T::RS96, T::C5_SS);
