@@ -118,21 +118,10 @@ struct SConv {
                 if (C::XLO) x[c % XS][i][1] = *reinterpret_cast<const half8*>(in_lo + off + (tile0(g) + i) * 16 * C::IRS);
             }
         };
-#ifdef TRK2_STAMP_L1
-        unsigned long long st_[4];
-        constexpr bool ST_ = C::KSTACK > 0;
-        if (ST_) st_[0] = hm_stamp();
-#endif
         static_for<0, (C::XD < NB ? C::XD : NB)>(reads);
-#ifdef TRK2_STAMP_L1
-        if (ST_) st_[1] = hm_stamp();
-#endif
 
         static_for<0, NB>([&](auto c_) __attribute__((always_inline)) {
             constexpr int c = decltype(c_)::value, g = c / KB, kb = c % KB, G = gs[g];
-#ifdef TRK2_STAMP_L1
-            if constexpr (kb == 0 && g > 0 && g < 3) { if (ST_) { unsigned long long t_ = hm_stamp(); if (blockIdx.x == 0 && lane == 0) atomicAdd(&g_trunk_stamp[tid >> 6][19 + g], t_ - st_[1]); } }
-#endif
             if constexpr (kb == 0) {
 #pragma unroll
                 for (int i = 0; i < G; ++i)
@@ -156,18 +145,11 @@ struct SConv {
             }
             constexpr int NA = g > 0 ? gs[g > 0 ? g - 1 : 0] * NTW : 0;  // accumulators of the previous group
             constexpr int A0 = kb * NA / KB, A1 = (kb + 1) * NA / KB;
-#ifndef TRK2_NOEPI
             if constexpr (g > 0) {
 #pragma unroll
                 for (int a = A0; a < A1; ++a)
                     epi((tile0(g - 1) + a / NTW) * 16 + li, (nt0 + a % NTW) * 16 + 4 * lk, acc[(g - 1) & 1][a / NTW][a % NTW]);
             }
-#else
-            if constexpr (g > 0) {
-#pragma unroll
-                for (int a = A0; a < A1; ++a) asm volatile("" ::"v"(acc[(g - 1) & 1][a / NTW][a % NTW]));
-            }
-#endif
             if constexpr (c >= 2 && c < CS + 2)
                 *reinterpret_cast<half8*>(cp.g + (size_t)crow[(c - 2) % 3] * 256 + (lane & 31) * 8) = cdat[(c - 2) & 1];
             if constexpr (c >= 1 && c < CS + 1)
@@ -197,7 +179,6 @@ struct SConv {
                     if constexpr (now) W.w[kb2][j2][p2] = wp[(size_t)(j2 * CNN::KB + kb2) * CNN::WSTR + 64 * p2];
                 });
             }
-#ifndef TRK2_NOSCHED
             {   // the block's LDS reads ride between its first MFMAs, the previous group's epilogue between the others
                 constexpr int ND = gs_at((c + C::XD) / KB) * (C::XLO ? 2 : 1);
                 constexpr int NM = C::NTERM * G * NTW;
@@ -217,28 +198,14 @@ struct SConv {
                     if (c <= CS + 1) __builtin_amdgcn_sched_group_barrier(0x140, 1, 0);
                 }
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         });
-#ifdef TRK2_STAMP_L1
-        if (ST_) st_[2] = hm_stamp();
-#endif
         {
             constexpr int g = NG - 1;
 #pragma unroll
             for (int a = 0; a < gs[g] * NTW; ++a)
                 epi((tile0(g) + a / NTW) * 16 + li, (nt0 + a % NTW) * 16 + 4 * lk, acc[g & 1][a / NTW][a % NTW]);
         }
-#ifdef TRK2_STAMP_L1
-        if (ST_ && blockIdx.x == 0) {
-            st_[3] = hm_stamp();
-            if (lane == 0) {
-                atomicAdd(&g_trunk_stamp[tid >> 6][17], st_[1] - st_[0]);
-                atomicAdd(&g_trunk_stamp[tid >> 6][18], st_[2] - st_[1]);
-                atomicAdd(&g_trunk_stamp[tid >> 6][19], st_[3] - st_[2]);
-            }
-        }
-#endif
     }
 };
 

@@ -574,7 +574,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
     }
     int slot = 0, g_first = g_begin;  // groups g_first, g_first + 1, ... wait in ring slots 0 .. slot-1
 #ifdef HM_TRUNK_STAMP
-    unsigned long long tts[12], tacc[12] = {};
+    unsigned long long tts[14], tacc[12] = {};
     unsigned long long tn = 0;
     const bool tst = blockIdx.x == 0 && GATHER;
 #define TTS(i) do { if (tst) tts[i] = hm_stamp(); } while (0)
@@ -591,8 +591,15 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         TTS(0);
 
         // (wave grids 2x3, 1x6, 4x1 and weight prefetch depths 4, 5 measured the same or worse in same-session A/Bs)
+#ifdef HM_TRUNK_STAMP
+        ConvH<NW, 96, 3, 96, T::L5, T::RS96, 4, 2, 3, S, T::IN_SS, 0, (W16T < 2)>::run(
+            h0, l0, wf(4), EpiPlanesS<T::L5, T::RS96, T::C5_SS>{h1, l1, W.bias[4]},
+            [&](int i) __attribute__((always_inline)) { if (tst) tts[10 + i] = hm_stamp(); });
+        if (tst) { tacc[10] += tts[10] - tts[0]; tacc[11] += tts[11] - tts[10]; }
+#else
         ConvH<NW, 96, 3, 96, T::L5, T::RS96, 4, 2, 3, S, T::IN_SS, 0, (W16T < 2)>::run(
             h0, l0, wf(4), EpiPlanesS<T::L5, T::RS96, T::C5_SS>{h1, l1, W.bias[4]});
+#endif
         zero_pad_rows_h<S, T::L5, 96>(h1, l1, T::RS96, T::C5_SS);
         TTS(1);
         __syncthreads();
@@ -758,6 +765,8 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
     if (tst && (threadIdx.x & 63) == 0) {
         for (int i = 0; i < 10; ++i) atomicAdd(&g_tail_stamp[threadIdx.x >> 6][i], tacc[i]);
         atomicAdd(&g_tail_stamp[threadIdx.x >> 6][10], tn);
+        atomicAdd(&g_tail_stamp[threadIdx.x >> 6][11], tacc[10]);
+        atomicAdd(&g_tail_stamp[threadIdx.x >> 6][12], tacc[11]);
     }
 #endif
 #undef TTS

@@ -330,30 +330,14 @@ struct EpiE4S {
     __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
         half4 h, l;
         split4(acc, h, l);
-#ifdef TRK2_NOE4
-        asm volatile("" ::"v"(h), "v"(l));
-        return;
-#endif
+
         *reinterpret_cast<half4*>(g + (size_t)m * (2 * C4_CH) + col) = h;
         *reinterpret_cast<half4*>(g + (size_t)m * (2 * C4_CH) + C4_CH + col) = l;
     }
 };
 
-struct CopyRows3 {  // the same rows over three waves
-#ifdef TRK2_NOCOPY
-    static constexpr int CS = 0, NWV = 3;
-#else
-    static constexpr int CS = (TR_OWN / 2 + 2) / 3, NWV = 3;
-#endif
-    const uint8_t* rows;
-    half_t* g;
-};
 struct CopyRows {
-#ifdef TRK2_NOCOPY
-    static constexpr int CS = 0, NWV = 4;
-#else
     static constexpr int CS = TR_CS, NWV = 4;
-#endif
     const uint8_t* rows;  // LDS: this layer's list of TR_OWN row numbers
     half_t* g;            // map row of tile row 0
 };
@@ -365,7 +349,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void trunk2_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views, int ctx, const RInfo* __restrict__ rinfo,
                    const uint8_t* __restrict__ bases, const uint32_t* __restrict__ kin, const uint8_t* __restrict__ sctx,
                    CtxWeights W, TrunkMaps mp) {
-    using G = EdgeGeo<K1>;
     constexpr int NW = 4;
     __shared__ __attribute__((aligned(16))) half_t smem[TR_LDS_HALVES + TR_XROWS * TR_WRS];
     __shared__ uint32_t rlist[2][3 * 32];  // the tile's row lists ([3][128] bytes, entries past TR_OWN stay 0); two buffers: conv4
@@ -433,27 +416,15 @@ void trunk2_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         if (r < TR_RL / 4) rlist[buf][r / (TR_OWN / 4) * 32 + r % (TR_OWN / 4)] = bd.rl;
     };
 
-#ifndef TRK2_XD
-#define TRK2_XD 1
-#endif
-#ifndef TRK2_XD1
-#define TRK2_XD1 2
-#endif
-    using C1 = SCfg<8, (2 * K1 + 3) / 4 * 4, TR_WRS, 1, true, false, K1, TRK2_XD1>;
-    using C2 = SCfg<128, 3, TR_RS, 2, !W16, true, 0, TRK2_XD>;
-    using C3 = SCfg<128, 3, TR_RS, 4, !W16, true, 0, TRK2_XD>;
-#ifndef TRK2_C4W4  // conv4 on three waves, two channel tiles each, all positions (three tiles x half the positions on four
-                  // waves needs 288 weight registers per wave and spills: scratch traffic shares the vector-memory counter)
-    using C4 = SCfg<128, 3, TR_RS, 8, !W16, true, 0, TRK2_XD, 2>;
-    using L4a = SConv<C4, C1, 0, 4, 3>;
-    using L4b = L4a;
+    using C1 = SCfg<8, (2 * K1 + 3) / 4 * 4, TR_WRS, 1, true, false, K1, 2>;
+    using C2 = SCfg<128, 3, TR_RS, 2, !W16, true, 0, 1>;
+    using C3 = SCfg<128, 3, TR_RS, 4, !W16, true, 0, 1>;
+    // conv4 (96 channels) on three waves, two channel tiles each, all positions; the fourth copies the E3 rows out.  (Three
+    // tiles x half the positions on four waves needs 288 weight registers per wave and spills: scratch traffic shares the
+    // vector-memory counter and every wait behind it becomes conservative.)
+    using C4 = SCfg<128, 3, TR_RS, 8, !W16, true, 0, 1, 2>;
+    using L4 = SConv<C4, C1, 0, 4, 3>;
     const int nt04 = wave < 3 ? 2 * wave : 4;
-#else
-    using C4 = SCfg<128, 3, TR_RS, 8, !W16, true, 0, TRK2_XD, 3>;  // 96 channels: a wave takes 3 channel tiles x half the positions
-    using L4a = SConv<C4, C1, 0, 2, 2>;
-    using L4b = SConv<C4, C1, 4, 2, 1>;
-    const int nt04 = 3 * (wave & 1);
-#endif
     using L1 = SConv<C1, C2, 0, 3, 3, 3>;
     using L2 = SConv<C2, C3, 0, 2, 3, 4>;  // the longest group last: it is the window in which conv3's weights can be fetched
     using L3 = SConv<C3, C4, 0, 4, 4>;
@@ -509,17 +480,25 @@ void trunk2_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         __syncthreads();
         TS(6);
         const EpiE4S e4{reinterpret_cast<half_t*>(mp.e4) + (size_t)grow0 * (2 * C4_CH)};
-#ifndef TRK2_C4W4
         if (wave < 3) {
-            L4a::run(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0, CopyRows3{rl + 256, g3});
-        } else {
+            L4::run(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0);
+        } else {  // the fourth wave has no channels in conv4: it copies the flagged E3 rows out (all 56 two-row slots)
             sconv_load_bias<C1>(W.c1f_bias, nt0, lane, wr);
             sconv_load_w<C1, 0, C1::KB>(c1f, nt0, lane, wr);
+            const uint8_t* cpr = rl + 256 + (lane >> 5);
+            half8 cd[4];
+#pragma unroll
+            for (int q0 = 0; q0 < TR_OWN / 2; q0 += 4) {
+                int row[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) row[q] = cpr[2 * (q0 + q)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    cd[q] = *reinterpret_cast<const half8*>(((lane & 16) ? a_lo : a_hi) + row[q] * TR_RS + (lane & 15) * 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<half8*>(g3 + (size_t)row[q] * 256 + (lane & 31) * 8) = cd[q];
+            }
         }
-#else
-        if (wave < 2) L4a::run(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0, CopyRows{rl + 256, g3});
-        else L4b::run(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0, CopyRows{rl + 256, g3});
-#endif
         build_store(buf ^ 1);
         buf ^= 1;
         TS(7);
@@ -592,14 +571,16 @@ struct EpiSpec {
     }
 };
 
-// conv1's edge outputs: the folded bn0 constant must not count for the tap on the zero padding (c1f_corr, hm_weights.cpp)
+// conv1's edge outputs: the folded bn0 constant must not count for the tap on the zero padding (c1f_corr, hm_weights.cpp);
+// a lane's four channels of the two correction rows are loaded before the layer (in the epilogue the load would queue
+// behind the map-row requests)
 struct EpiSpecC1 {
     half_t* hi;
     half_t* lo;
     const float* __restrict__ bias;
-    const float* __restrict__ corr;  // [2][128]: first output row, last output row
+    float4 c0, c1;  // first output row (left chains), last output row (right chains)
     __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
-        const float4 c = *reinterpret_cast<const float4*>(corr + (m >= EG_S ? 128 : 0) + col);
+        const float4 c = m >= EG_S ? c1 : c0;
         half4 h, l;
         split4(f32x4{acc[0] - c.x, acc[1] - c.y, acc[2] - c.z, acc[3] - c.w}, h, l);
         *reinterpret_cast<half4*>(hi + m * TR_RS + col) = h;
@@ -647,7 +628,10 @@ __global__ __launch_bounds__(512) void edge_kernel(SiteRange sr, const RInfo* __
     // one 3-tap layer over the staged operand rows [pseudo-row][tap][128]
     using CE128 = ConvH<NW, 128, 3, 128, 1, TR_RS, 1, 8, 3, EG_M, 3 * TR_RS, 0, !W16, true, false, 0, false, 0, 1, 1>;
     using CE96 = ConvH<NW, 128, 3, C4_CH, 1, TR_RS, 1, 6, 3, EG_M, 3 * TR_RS, 0, !W16, true, false, 0, false, 0, 1, 1>;
-    using C1E = ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, 1, TR_WRS, 1, 8, 4, EG_M, EG_XROWS * TR_WRS, 0, true, false, false, K1, false, 0, 1, 1>;
+    // all of conv1's weight blocks are requested in its prologue (ring depth = blocks + 1): the map rows can then be
+    // requested right behind them, before the first MFMA, without standing in front of any later weight load
+    constexpr int KB1E = (2 * K1 + 3) / 4 * 4 * 8 / 32;
+    using C1E = ConvH<NW, 8, (2 * K1 + 3) / 4 * 4, 128, 1, TR_WRS, 1, 8, KB1E + 1, EG_M, EG_XROWS * TR_WRS, 0, true, false, false, K1, false, 0, 1, 1>;
 
     // Site descriptors + feature rows of the pass that starts at site s0, by threads [0, nt) (t < 0: not taking part).
     // A dependent chain of loads (site -> read -> base) followed by 1024 row builds: done for the NEXT pass by the two
@@ -808,9 +792,13 @@ __global__ __launch_bounds__(512) void edge_kernel(SiteRange sr, const RInfo* __
         ETS(0);
         const int sn = s0 + gridDim.x * EG_S;
         desc_a(sn);
-        request(L2t{});
-        C1E::run(xb, xb, reinterpret_cast<const half_t*>(W.c1f), EpiSpecC1{sp_hi, sp_lo, W.c1f_bias, W.c1f_corr});
-        // (conv1 first, the layer-2 rows requested behind its loads, was tried: this phase 12.7 k -> 14.4 k cycles)
+        {
+            const int col = (threadIdx.x >> 6) * 16 + 4 * ((threadIdx.x & 63) >> 4);  // this lane's channels in conv1 (1 x 8 wave grid)
+            const EpiSpecC1 epi1{sp_hi, sp_lo, W.c1f_bias, *reinterpret_cast<const float4*>(W.c1f_corr + col),
+                                 *reinterpret_cast<const float4*>(W.c1f_corr + 128 + col)};
+            C1E::run(xb, xb, reinterpret_cast<const half_t*>(W.c1f), epi1,
+                     [&](int i) __attribute__((always_inline)) { if (i == 0) request(L2t{}); });
+        }
         request(L3t{});
         request(L4t{});
         ETS(1);

@@ -64,5 +64,7 @@ nt = float(tb[0, 10])
 print("tail passes of workgroup 0:", int(nt), " fc batches", int(tb[0, 9]))
 for i, nm in enumerate(["conv5", "barrier", "conv6|stage", "barrier", "conv7|stage", "barrier", "conv8|stage"]):
     print(f"tail {nm:14s} " + " ".join(f"{x:7.0f}" for x in tb[:, i].astype(float) / nt))
+print("tail conv5: barrier -> prologue loads issued " + " ".join(f"{x:7.0f}" for x in tb[:, 11].astype(float) / nt))
+print("tail conv5: k-loop                          " + " ".join(f"{x:7.0f}" for x in tb[:, 12].astype(float) / nt))
 print("tail fc1+fc2 per pass " + " ".join(f"{x:7.0f}" for x in tb[:, 8].astype(float) / nt))
 print("tail sum            " + " ".join(f"{x:7.0f}" for x in (tb[:, :7].astype(float).sum(1) + tb[:, 8]) / nt))
