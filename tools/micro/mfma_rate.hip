@@ -4,7 +4,7 @@
 #include <cstdio>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k(float* out, unsigned long long* t, int iters) {
+__global__ __launch_bounds__(512) void k(float* out, unsigned long long* t, int iters) {
     half8 a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.5f); }
     f32x4 acc[8] = {};
@@ -27,18 +27,19 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* t, int 
 }
 int main() {
     float* out; unsigned long long* t;
-    hipMalloc(&out, 256 * 256 * 4); hipMalloc(&t, 256 * 8);
+    (void)hipMalloc(&out, 256 * 512 * 4); (void)hipMalloc(&t, 256 * 8);
     const int iters = 20000;
-    for (int rep = 0; rep < 3; ++rep) {
+    for (int rep = 0; rep < 6; ++rep) {
+        const int threads = rep < 3 ? 256 : 512;  // one, then two waves per SIMD
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k, dim3(256), dim3(256), 0, 0, out, t, iters);
+        hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, out, t, iters);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned long long h[256]; hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost);
         double cyc = (double)h[0];
-        printf("rep %d: %.3f ms, stamp ticks %.0f -> %.2f ticks per MFMA, tick rate %.3f GHz, %.1f TFLOP/s chip-wide\n", rep, ms, cyc,
-               cyc / (iters * 8.0), cyc / (ms * 1e6), 256.0 * 4 * iters * 8 * 16384.0 / (ms * 1e-3) / 1e12);
+        printf("%d waves/SIMD: %.3f ms, stamp ticks %.0f -> %.2f ticks per MFMA and wave, tick rate %.3f GHz, %.1f TFLOP/s chip-wide\n", threads / 256, ms, cyc,
+               cyc / (iters * 8.0), cyc / (ms * 1e6), 256.0 * (threads / 64) * iters * 8 * 16384.0 / (ms * 1e-3) / 1e12);
     }
     return 0;
 }
