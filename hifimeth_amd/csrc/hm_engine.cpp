@@ -158,7 +158,7 @@ struct hm_engine {
     // so the trunk wins above ~1.7 % sites per base (CHH, two views: 3.3 %) -- everything but CpG-only runs on
     // CpG-poor genomes.  Both paths give the same calls to within fp32 re-association.
     int trunk = 2;
-    int trunk_impl = 1;  // 1: streaming 4-wave trunk kernel (hm_convs.h), 0: the 8-wave ConvH form
+    int trunk_impl = 1;  // 1: streaming 4-wave trunk kernel (hm_convs.h), 2: the same on 8 waves, 0: the 8-wave ConvH form
     double density[3] = {-1, -1, -1};  // sites per base of the last finished batch (-1: none yet -> trunk)
     int64_t group_bases = int64_t(2) << 20;  // reads per trunk group: their maps take ~3.9 KB per base
     bool stamps_on = false;
@@ -552,8 +552,13 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
             }
             {
                 Span sp(e, spans, K_TRUNK, c, 0, (int64_t)n_tiles * TR_OWN * n_views);
-                (e->trunk_impl ? launch_trunk2 : launch_trunk)(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
-                             b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->num_cu, w16);
+                if (e->trunk_impl)
+                    launch_trunk2(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
+                                  b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->num_cu, w16,
+                                  e->trunk_impl == 2);
+                else
+                    launch_trunk(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
+                                 b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->num_cu, w16);
                 sp.end();
             }
             {
@@ -775,7 +780,7 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
         e->trunk = (int)value;
         for (double& d : e->density) d = -1;
     } else if (k == "trunk_impl") {
-        if (value < 0 || value > 1) return HM_EINVAL;
+        if (value < 0 || value > 2) return HM_EINVAL;
         e->trunk_impl = (int)value;
     } else if (k == "group_bases") {
         if (value < 1) return fail(e, HM_EINVAL, "group_bases must be positive");

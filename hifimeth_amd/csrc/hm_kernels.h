@@ -73,7 +73,7 @@ void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w
                         const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, int w16_level);
 void launch_trunk2(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,
-                   const TrunkMaps& maps, int grid, bool w16);
+                   const TrunkMaps& maps, int grid, bool w16, bool waves8 = false);
 // the same path in strict fp32 (precision 0; hm_trunk_f32.hip): fp32 maps and edge rows, v_mfma_f32_16x16x4_f32
 void launch_trunk_f32(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                       const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,

@@ -52,9 +52,8 @@ constexpr int TR_WRS = 8;      // feature row = 8 exact halves
 constexpr int TR_AROWS = 148, TR_BROWS = 144;
 static_assert(TR_M1 + 4 <= TR_AROWS && TR_M3 + 8 <= TR_BROWS && TR_M4 + 16 <= TR_M3, "halo plan");
 constexpr int TR_LDS_HALVES = 2 * TR_AROWS * TR_RS + 2 * TR_BROWS * TR_RS;
-constexpr int TR_CS = TR_OWN / 8;   // streaming trunk: copy slots per wave and layer: 4 waves x 2 rows x 14 = every own row of the tile
 constexpr int TR_RL = 3 * TR_OWN;   // bytes of a tile's row lists (rowlist_kernel)
-static_assert(TR_OWN % 8 == 0 && TR_RL % 4 == 0, "row lists");
+static_assert(TR_OWN % 16 == 0 && TR_RL % 4 == 0, "row lists; copy slots of two rows over 4 or 8 waves");
 
 // ReLU + split -> LDS planes (row m, no padding rows: the dense form has none); the rows an edge chain will read also
 // go to the HBM map as [hi 128 | lo 128].  (Measured: all map stores together cost 11 % of the kernel.  Staging them in
@@ -336,20 +335,23 @@ struct EpiE4S {
     }
 };
 
+template <int NWV_>
 struct CopyRows {
-    static constexpr int CS = TR_CS, NWV = 4;
+    static constexpr int NWV = NWV_, CS = TR_OWN / (2 * NWV_);  // NWV waves x 2 rows x CS slots = every own row of the tile
     const uint8_t* rows;  // LDS: this layer's list of TR_OWN row numbers
     half_t* g;            // map row of tile row 0
 };
 
 }  // namespace
 
-template <int K1, bool W16>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+// NW = 4: one wave per SIMD, 32 channels per wave (the default).  NW = 8: two waves per SIMD, 16 channels per wave -- twice
+// the LDS operand reads, but two waves can issue MFMAs 14 % faster than one (tools/micro/mfma_rate.hip).
+template <int K1, bool W16, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 void trunk2_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views, int ctx, const RInfo* __restrict__ rinfo,
                    const uint8_t* __restrict__ bases, const uint32_t* __restrict__ kin, const uint8_t* __restrict__ sctx,
                    CtxWeights W, TrunkMaps mp) {
-    constexpr int NW = 4;
+    constexpr int NTW = 8 / NW;  // channel tiles per wave in the 128-channel layers
     __shared__ __attribute__((aligned(16))) half_t smem[TR_LDS_HALVES + TR_XROWS * TR_WRS];
     __shared__ uint32_t rlist[2][3 * 32];  // the tile's row lists ([3][128] bytes, entries past TR_OWN stay 0); two buffers: conv4
                                           // still copies E3 rows while the next tile's arrive
@@ -416,15 +418,16 @@ void trunk2_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         if (r < TR_RL / 4) rlist[buf][r / (TR_OWN / 4) * 32 + r % (TR_OWN / 4)] = bd.rl;
     };
 
-    using C1 = SCfg<8, (2 * K1 + 3) / 4 * 4, TR_WRS, 1, true, false, K1, 2>;
-    using C2 = SCfg<128, 3, TR_RS, 2, !W16, true, 0, 1>;
-    using C3 = SCfg<128, 3, TR_RS, 4, !W16, true, 0, 1>;
+    using C1 = SCfg<8, (2 * K1 + 3) / 4 * 4, TR_WRS, 1, true, false, K1, 2, NTW>;
+    using C2 = SCfg<128, 3, TR_RS, 2, !W16, true, 0, 1, NTW>;
+    using C3 = SCfg<128, 3, TR_RS, 4, !W16, true, 0, 1, NTW>;
     // conv4 (96 channels) on three waves, two channel tiles each, all positions; the fourth copies the E3 rows out.  (Three
     // tiles x half the positions on four waves needs 288 weight registers per wave and spills: scratch traffic shares the
     // vector-memory counter and every wait behind it becomes conservative.)
-    using C4 = SCfg<128, 3, TR_RS, 8, !W16, true, 0, 1, 2>;
+    using C4 = SCfg<128, 3, TR_RS, 8, !W16, true, 0, 1, NTW>;
     using L4 = SConv<C4, C1, 0, 4, 3>;
-    const int nt04 = wave < 3 ? 2 * wave : 4;
+    constexpr int NW4 = 6 / NTW;  // waves with channels in conv4
+    const int nt04 = wave < NW4 ? NTW * wave : 6 - NTW;
     using L1 = SConv<C1, C2, 0, 3, 3, 3>;
     using L2 = SConv<C2, C3, 0, 2, 3, 4>;  // the longest group last: it is the window in which conv3's weights can be fetched
     using L3 = SConv<C3, C4, 0, 4, 4>;
@@ -432,7 +435,7 @@ void trunk2_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     static_assert(TR_XROWS <= NW * 64, "one feature row per thread");
     auto wf = [&](int i) { return reinterpret_cast<const half_t*>(W.wfrag_h[i]); };
     const half_t* c1f = reinterpret_cast<const half_t*>(W.c1f);
-    const int nt0 = 2 * wave;
+    const int nt0 = NTW * wave;
 
     WRegs wr;
     sconv_load_w<C1, 0, C1::KB>(c1f, nt0, lane, wr);
@@ -469,26 +472,28 @@ void trunk2_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         __syncthreads();
         TS(2);
         build_desc2();
-        L2::run(a_hi, a_lo, wr, EpiTrunkS{b_hi, b_lo}, wf(2), W.bias[2], nt0, nt0, CopyRows{rl, g1});
+        L2::run(a_hi, a_lo, wr, EpiTrunkS{b_hi, b_lo}, wf(2), W.bias[2], nt0, nt0, CopyRows<NW>{rl, g1});
         TS(3);
         __syncthreads();
         TS(4);
         build_desc3();
         build_loads();
-        L3::run(b_hi, b_lo, wr, EpiTrunkS{a_hi, a_lo}, wf(3), W.bias[3], nt0, nt04, CopyRows{rl + 128, g2});
+        L3::run(b_hi, b_lo, wr, EpiTrunkS{a_hi, a_lo}, wf(3), W.bias[3], nt0, nt04, CopyRows<NW>{rl + 128, g2});
         TS(5);
         __syncthreads();
         TS(6);
         const EpiE4S e4{reinterpret_cast<half_t*>(mp.e4) + (size_t)grow0 * (2 * C4_CH)};
-        if (wave < 3) {
+        if (wave < NW4) {
             L4::run(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0);
-        } else {  // the fourth wave has no channels in conv4: it copies the flagged E3 rows out (all 56 two-row slots)
+        } else {  // a quarter of the waves has no channels in conv4: they copy the flagged E3 rows out (56 two-row slots)
             sconv_load_bias<C1>(W.c1f_bias, nt0, lane, wr);
             sconv_load_w<C1, 0, C1::KB>(c1f, nt0, lane, wr);
-            const uint8_t* cpr = rl + 256 + (lane >> 5);
+            constexpr int NCW = NW - NW4, QW = TR_OWN / 2 / NCW;  // copying waves, slots per wave
+            static_assert(QW % 4 == 0, "copy slots in fours");
+            const uint8_t* cpr = rl + 256 + 2 * QW * (wave - NW4) + (lane >> 5);
             half8 cd[4];
 #pragma unroll
-            for (int q0 = 0; q0 < TR_OWN / 2; q0 += 4) {
+            for (int q0 = 0; q0 < QW; q0 += 4) {
                 int row[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) row[q] = cpr[2 * (q0 + q)];
@@ -861,13 +866,14 @@ void launch_trunk(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, i
 
 void launch_trunk2(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,
-                   const TrunkMaps& maps, int grid, bool w16) {
+                   const TrunkMaps& maps, int grid, bool w16, bool waves8) {
     if (n_tiles <= 0) return;
-    const dim3 g(min(n_tiles * n_views, grid)), b(256);
+    const dim3 g(min(n_tiles * n_views, grid)), b(waves8 ? 512 : 256);
     if (k1 == 11) hipLaunchKernelGGL(rowlist_kernel<11>, dim3(n_tiles * n_views), dim3(128), 0, st, tiles, n_tiles, ctx, rinfo, bases, sctx, maps.rowlist);
     else hipLaunchKernelGGL(rowlist_kernel<13>, dim3(n_tiles * n_views), dim3(128), 0, st, tiles, n_tiles, ctx, rinfo, bases, sctx, maps.rowlist);
 #define HM_TRUNK(K1, W16) \
-    hipLaunchKernelGGL((trunk2_kernel<K1, W16>), g, b, 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, sctx, w, maps)
+    do { if (waves8) hipLaunchKernelGGL((trunk2_kernel<K1, W16, 8>), g, b, 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, sctx, w, maps); \
+         else hipLaunchKernelGGL((trunk2_kernel<K1, W16, 4>), g, b, 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, sctx, w, maps); } while (0)
     if (k1 == 11) { if (w16) HM_TRUNK(11, true); else HM_TRUNK(11, false); }
     else { if (w16) HM_TRUNK(13, true); else HM_TRUNK(13, false); }
 #undef HM_TRUNK

@@ -93,7 +93,7 @@ const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a fa
  * conv2..conv8, the literal configs[4], which misses that bar (max |dp| ~ 2.5e-3): kept for the record; activations stay
  * split and accumulation fp32 in every mode), "trunk" (2 = per context by site density, default; 1 = conv1..conv4 once per
  * read position; 0 = once per site; every precision has both forms), "trunk_impl" (1 = streaming 4-wave trunk kernel,
- * default; 0 = the 8-wave form; byte-identical results), "group_bases" (reads per trunk group, default 2 Mi bases),
+ * default; 2 = the same on 8 waves; 0 = the 8-wave ConvH form; byte-identical results), "group_bases" (reads per trunk group, default 2 Mi bases),
  * "stamps" (diagnostic) */
 int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
 

@@ -531,10 +531,10 @@ def test_streaming_trunk_is_byte_identical_to_the_8_wave_form():
     from hifimeth_amd import MethylationCaller
     reads = _mixed_reads() + synth_reads(6, seed=77, median_len=5000, sigma=0.5, frac_wide=0.3)
     out = []
-    for impl in (0, 1):
+    for impl in (0, 1, 2):  # 8-wave ConvH form, streaming on 4 waves (default), streaming on 8 waves
         with MethylationCaller(device=0) as m:
             m.set_option("trunk", 1)
             m.set_option("trunk_impl", impl)
             out.append(m.call(reads).copy())
-    assert len(out[0]) == len(out[1]) > 1000
-    assert out[0].tobytes() == out[1].tobytes()
+    assert len(out[0]) == len(out[1]) == len(out[2]) > 1000
+    assert out[0].tobytes() == out[1].tobytes() == out[2].tobytes()

@@ -11,7 +11,7 @@ mc.set_option("trunk", 1)
 mc.submit_all(reads)
 mc.upload()
 for rep in range(3):
-    for impl in (0, 1):
+    for impl in (0, 1, 2):
         mc.set_option("trunk_impl", impl)
         mc.run(); mc.sync()
         mc.timing(reset=True)
