@@ -10,9 +10,13 @@
 // of 197 / 99 / 50 / 25 positions per site: ~5x fewer MACs at the site density of an all-context run, with identical
 // products (same weights, same inputs, fp32 accumulation; only the summation order inside the MFMA differs).
 //
-//   trunk_kernel : one workgroup per tile of 112 view positions: feature rows -> E1 -> E2 -> E3 in LDS (split fp16
+//   trunk2_kernel: one workgroup per tile of 112 view positions: feature rows -> E1 -> E2 -> E3 in LDS (split fp16
 //                  planes, a-trous implicit GEMM on v_mfma_f32_16x16x32_f16, M = 144 / 144 / 128 / 112 rows: no ragged
 //                  tiles) -> E4 to HBM; the E1..E3 rows that some site's edge chain needs are written out as well.
+//                  Streaming form (hm_convs.h): 4 waves, a layer's weights resident in registers, the positions
+//                  streamed past them in tile groups, the epilogue between the next group's MFMAs (the default).
+//   trunk_kernel : the same tile in the 8-wave ConvH form (engine option trunk_impl = 0; byte-identical results).
+//   rowlist_kernel: per tile and layer, the rows an edge chain will read (trunk2_kernel copies exactly those out).
 //   edge_kernel  : the first and last conv4 row of every site (the only two that are not samples of E4): per side a
 //                  chain of four one-row layers over rows gathered from the maps, 32 sites stacked along M.
 //   The tail kernel (hm_front_h.hip, GATHER) then picks a site's 23 interior conv4 rows out of E4 + its two edge rows.
