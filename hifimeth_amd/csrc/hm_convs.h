@@ -16,8 +16,26 @@
 namespace hm {
 
 struct WRegs {
-    half8 w[12][3][2];  // [k-block][n-tile][plane hi / lo]; a layer uses its first NTW n-tiles
-    float4 bz[3];
+    half8 w[12][4][2];  // [k-block][n-tile][plane hi / lo]; a layer uses its first NTW n-tiles
+    float4 bz[4];
+};
+
+// Row maps: where output row m of a layer finds its first tap in the input planes (halves).
+struct DenseRows {  // the dense trunk: row m of the tile, taps DIL rows apart
+    static constexpr bool DENSE = true;
+    static constexpr int M = 1 << 30;
+};
+// S sites stacked along M (tail kernel): m -> (site = m / LOUT, p = m % LOUT), a stride-MSTR conv inside the site's rows;
+// rows past M (the ragged last tile) re-read the last valid row and are not written
+template <int LOUT, int ISS, int MSTR, int ROW0, int M_>
+struct SiteRows {
+    static constexpr bool DENSE = false;
+    static constexpr int M = M_;
+    template <class C>
+    static __device__ __forceinline__ int off(int m) {
+        const int mc = m < M ? m : M - 1, site = mc / LOUT, p = mc - site * LOUT;
+        return site * ISS + (MSTR * p + ROW0) * C::IRS;
+    }
 };
 
 template <int CIN_, int KT_, int IRS_, int DIL_, bool WLO_, bool XLO_, int KSTACK_, int XD_, int NTW_ = 2>
@@ -75,9 +93,9 @@ __device__ __forceinline__ void sconv_load_bias(const float* __restrict__ bias, 
 // Copy: the rows of THIS layer's input planes that must also reach HBM (the map rows an edge chain reads) leave from here,
 // as whole 512-byte rows: CS fixed slots per wave, two rows per slot (one ds_read_b128 + one global_store_dwordx4 per lane,
 // the store one k-block behind its read), row numbers from a list in LDS that is padded with a row that is always valid.
-// T0: the first 16-row tile of this wave's share of the positions.
-template <class C, class CN, int T0, int... GS>
-struct SConv {
+// T0: the first 16-row tile of this wave's share of the positions.  RM: row map (DenseRows / SiteRows).
+template <class C, class CN, class RM, int T0, int... GS>
+struct SConvR {
     static constexpr int NG = sizeof...(GS);
     static constexpr int gs[NG] = {GS...};
     static constexpr int gmax() { int m = 0; for (int g = 0; g < NG; ++g) m = gs[g] > m ? gs[g] : m; return m; }
@@ -99,6 +117,12 @@ struct SConv {
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
         const int a0 = li * C::IRS;
+        constexpr int NTILES = tile0(NG) - T0;
+        int aoff[RM::DENSE ? 1 : NTILES];  // per tile: this lane's row in the input planes (site-stacked layers)
+        if constexpr (!RM::DENSE) {
+#pragma unroll
+            for (int t = 0; t < NTILES; ++t) aoff[t] = RM::template off<C>((T0 + t) * 16 + li);
+        }
         f32x4 acc[2][GMAX][NTW];
         half8 x[XS][GMAX][2];
         constexpr int CS = Copy::CS;
@@ -111,11 +135,14 @@ struct SConv {
 
         auto reads = [&](auto c_) __attribute__((always_inline)) {
             constexpr int c = decltype(c_)::value, g = c / KB, kb = c % KB;
-            const int off = a0 + C::lane_off(kb, lk);
+            const int off = C::lane_off(kb, lk);
 #pragma unroll
             for (int i = 0; i < gs[g]; ++i) {
-                x[c % XS][i][0] = *reinterpret_cast<const half8*>(in_hi + off + (tile0(g) + i) * 16 * C::IRS);
-                if (C::XLO) x[c % XS][i][1] = *reinterpret_cast<const half8*>(in_lo + off + (tile0(g) + i) * 16 * C::IRS);
+                int o;
+                if constexpr (RM::DENSE) o = a0 + off + (tile0(g) + i) * 16 * C::IRS;
+                else o = aoff[RM::DENSE ? 0 : tile0(g) + i - T0] + off;
+                x[c % XS][i][0] = *reinterpret_cast<const half8*>(in_hi + o);
+                if (C::XLO) x[c % XS][i][1] = *reinterpret_cast<const half8*>(in_lo + o);
             }
         };
         static_for<0, (C::XD < NB ? C::XD : NB)>(reads);
@@ -147,8 +174,10 @@ struct SConv {
             constexpr int A0 = kb * NA / KB, A1 = (kb + 1) * NA / KB;
             if constexpr (g > 0) {
 #pragma unroll
-                for (int a = A0; a < A1; ++a)
-                    epi((tile0(g - 1) + a / NTW) * 16 + li, (nt0 + a % NTW) * 16 + 4 * lk, acc[(g - 1) & 1][a / NTW][a % NTW]);
+                for (int a = A0; a < A1; ++a) {
+                    const int m = (tile0(g - 1) + a / NTW) * 16 + li;
+                    if ((tile0(g - 1) + a / NTW + 1) * 16 <= RM::M || m < RM::M) epi(m, (nt0 + a % NTW) * 16 + 4 * lk, acc[(g - 1) & 1][a / NTW][a % NTW]);
+                }
             }
             if constexpr (c >= 2 && c < CS + 2)
                 *reinterpret_cast<half8*>(cp.g + (size_t)crow[(c - 2) % 3] * 256 + (lane & 31) * 8) = cdat[(c - 2) & 1];
@@ -203,10 +232,15 @@ struct SConv {
         {
             constexpr int g = NG - 1;
 #pragma unroll
-            for (int a = 0; a < gs[g] * NTW; ++a)
-                epi((tile0(g) + a / NTW) * 16 + li, (nt0 + a % NTW) * 16 + 4 * lk, acc[g & 1][a / NTW][a % NTW]);
+            for (int a = 0; a < gs[g] * NTW; ++a) {
+                const int m = (tile0(g) + a / NTW) * 16 + li;
+                if ((tile0(g) + a / NTW + 1) * 16 <= RM::M || m < RM::M) epi(m, (nt0 + a % NTW) * 16 + 4 * lk, acc[g & 1][a / NTW][a % NTW]);
+            }
         }
     }
 };
+
+template <class C, class CN, int T0, int... GS>
+using SConv = SConvR<C, CN, DenseRows, T0, GS...>;
 
 }  // namespace hm
