@@ -518,6 +518,54 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
             }
         });
     };
+    // The same pieces with the lane's (site, window position, channel chunk) of every piece PRECOMPUTED: which unit of the
+    // input plane a lane writes depends on the piece and the thread only, not on the group, so a staging thread packs it once
+    // per kernel -- offset inside the site's rows (20 bits) | site carry (2) | kind 0 pad / 1 map row / 2 edge row (2) | unit
+    // inside the plane (1) -- and a piece then costs ~20 instead of ~60 instructions (the conv8 phase lasted as long as its
+    // staging waves' address arithmetic).
+    auto stage_desc = [&](auto plo_, auto phi_, auto w0_, auto nwv_, auto k_) __attribute__((always_inline)) -> uint32_t {
+        constexpr int P_LO = decltype(plo_)::value, W0 = decltype(w0_)::value, NWV = decltype(nwv_)::value, k = decltype(k_)::value;
+        const int wo = max(wave_id() - W0, 0);
+        const int t = 64 * wo + lane, tq = t / 13, t13 = t - 13 * tq;
+        constexpr int U0 = 64 * (P_LO + k * NWV), AQ = U0 / 13, AR = U0 % 13, BQ = AQ / (T::L4 + 2), BR_ = AQ % (T::L4 + 2);
+        const int s1 = AR + t13, c1 = s1 >= 13, ch = s1 - 13 * c1;
+        const int s2 = BR_ + tq + c1, c2 = (s2 >= T::L4 + 2) + (s2 >= 2 * (T::L4 + 2)), prow = s2 - (T::L4 + 2) * c2;
+        const int site = BQ + c2, pos = prow - 1;
+        const bool data = pos >= 0 && pos < C4_LEN && ch < 12 && site < S;
+        const bool edge = pos == 0 || pos == C4_LEN - 1;
+        const int rel = edge ? (pos ? 2 * C4_CH : 0) + ch * 8 : 16 * pos * (2 * C4_CH) + ch * 8;
+        return (data ? (uint32_t)rel : 0u) | ((uint32_t)c2 << 20) | ((data ? (edge ? 2u : 1u) : 0u) << 22) | ((U0 + t < UNITS ? 1u : 0u) << 24);
+    };
+    auto stage_fast = [&](auto pl_, auto plo_, auto phi_, auto w0_, auto nwv_, const int grp, const int32_t rows, const auto& desc) __attribute__((always_inline)) {
+        constexpr int PL = decltype(pl_)::value, P_LO = decltype(plo_)::value, P_HI = decltype(phi_)::value;
+        constexpr int W0 = decltype(w0_)::value, NWV = decltype(nwv_)::value;
+        constexpr int K = (P_HI - P_LO + NWV - 1) / NWV;
+        const int wo = wave_id() - W0;
+        const uint32_t plane0 = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) half_t*)(PL ? l0 : h0));
+        const half_t* e4p = e4 + PL * C4_CH;
+        const half_t* edp = edge4 + PL * C4_CH;
+        static_for_h<0, K>([&](auto k_) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_)::value;
+            constexpr int U0 = 64 * (P_LO + k * NWV), BQ = U0 / 13 / (T::L4 + 2);
+            if ((P_LO + (k + 1) * NWV <= P_HI) || P_LO + k * NWV + wo < P_HI) {
+                const uint32_t d = desc[k];
+                const int rel = d & 0xfffff, c2 = (d >> 20) & 3, kind = (d >> 22) & 3;
+                const int gs = grp * S + BQ + c2;
+                const int32_t ra = __builtin_amdgcn_readlane(rows, BQ < S ? BQ : S - 1), rb = __builtin_amdgcn_readlane(rows, BQ + 1 < S ? BQ + 1 : S - 1);
+                const int32_t rc = __builtin_amdgcn_readlane(rows, BQ + 2 < S ? BQ + 2 : S - 1);
+                const int32_t rowv = c2 == 0 ? ra : c2 == 1 ? rb : rc;
+                const half_t* sm = e4p + ((int64_t)rowv * (2 * C4_CH) + rel);
+                const half_t* se = edp + ((int64_t)gs * (4 * C4_CH) + rel);
+                const half_t* src = kind != 0 && gs < n_sites ? (kind == 2 ? se : sm) : zeros;
+                const uint32_t dst = plane0 + 1024u * (uint32_t)(P_LO + k * NWV + wo);
+                uint32_t keep;
+                if (U0 + 64 * NWV <= UNITS || (d >> 24))
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+        });
+    };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
@@ -553,6 +601,14 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
                                  // group it stages next (rows) / of the group after that (pend, requested a pass ahead)
     int it = 0;
     float4 phi[NHI], plo[NLO];
+    // staging descriptors of this thread: conv7 phase (waves 4..7: the lo plane's pieces behind conv6's output), conv8 phase
+    // (waves 4..7: the pieces that held conv6's output, both planes)
+    constexpr int KB_ = (PIECES - LOW_PIECES + 3) / 4, KC = (LOW_PIECES + 3) / 4;
+    uint32_t dB[KB_], dC[KC];
+    if constexpr (GATHER) {
+        static_for_h<0, KB_>([&](auto k_) __attribute__((always_inline)) { dB[decltype(k_)::value] = stage_desc(ILOW{}, IPCS{}, I4{}, I4{}, k_); });
+        static_for_h<0, KC>([&](auto k_) __attribute__((always_inline)) { dC[decltype(k_)::value] = stage_desc(I0{}, ILOW{}, I4{}, I4{}, k_); });
+    }
 
     // first group of this workgroup: staged by everybody
     if constexpr (GATHER) {
@@ -611,7 +667,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         // (explicit if / else on the wave id, not a call that returns early: the staged rows must not be live across
         //  the other waves' conv code or they spill)
         if (GATHER && wave >= 6) {  // spare in conv6: the hi plane's pieces behind conv6's output, by LDS-DMA
-            if (more) stage_set(I0{}, ILOW{}, IPCS{}, I6{}, I2{}, g + 1, rows);
+            if (more) stage_set(I0{}, ILOW{}, IPCS{}, I6{}, I2{}, g + 1, rows);  // (this phase lasts as long as conv6: no descriptors spent on it)
         } else if (wave >= 6) {  // spare in conv6: request sites 3..7 of the next group
             if (more) {
                 int tl = threadIdx.x;
@@ -640,7 +696,7 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
         if (dbg && dbg_layer == 6 && g == 0) dump_planes<T::L6, 96, T::RS96>(h0, l0, dbg);
 
         if (GATHER && wave >= 4) {  // spare in conv7: the same pieces of the lo plane
-            if (more) stage_set(I1{}, ILOW{}, IPCS{}, I4{}, I4{}, g + 1, rows);
+            if (more) stage_fast(I1{}, ILOW{}, IPCS{}, I4{}, I4{}, g + 1, rows, dB);
         } else if (wave >= 6) {  // spare in conv7: the requested rows -> buffer 0 (behind conv6's output)
             if (more) {
                 int tl = threadIdx.x;
@@ -682,8 +738,8 @@ __global__ __launch_bounds__(512) void tail_kernel_h(const float* __restrict__ a
 
         if (GATHER && wave >= 4) {  // spare in conv8: the pieces that held conv6's output (dead since the last barrier)
             if (more) {
-                stage_set(I0{}, I0{}, ILOW{}, I4{}, I4{}, g + 1, rows);
-                stage_set(I1{}, I0{}, ILOW{}, I4{}, I4{}, g + 1, rows);
+                stage_fast(I0{}, I0{}, ILOW{}, I4{}, I4{}, g + 1, rows, dC);
+                stage_fast(I1{}, I0{}, ILOW{}, I4{}, I4{}, g + 1, rows, dC);
             }
             pend = load_row(g + 2, lane & (S - 1));
             // everything this wave staged for the next group is in LDS before it reaches the barrier in front of conv5
