@@ -36,7 +36,7 @@ n = float(buf[0, 16])
 print("tiles of workgroup 0:", int(n), " sites", mc.num_sites(3))
 streaming = not buf[:, 1].any()  # trunk2_kernel stamps a layer as a whole (slot 0) and the wait at its barrier (slot 3)
 names = ["layer", "", "", "barrier"] if streaming else ["prologue", "k-loop", "epilogue", "barrier"]
-print("shader-clock cycles per tile, one column per wave of workgroup 0" + (" (streaming form: 4 waves)" if streaming else ""))
+print("s_memtime ticks per tile (shares, not clock cycles), one column per wave of workgroup 0" + (" (streaming form: 4 waves)" if streaming else ""))
 tot = np.zeros(8)
 for l in range(4):
     for ph in range(4):
