@@ -597,6 +597,7 @@ int cmd_modstats(int argc, char** argv) {
 
 int cmd_pileup(int argc, char** argv);   // hifimeth_pileup.cpp
 int cmd_fastats(int argc, char** argv);  // hifimeth_pileup.cpp
+int cmd_thresholds(int argc, char** argv);
 int cmd_corr(int argc, char** argv);     // hifimeth_pileup.cpp
 int cmd_cov2bed(int argc, char** argv);  // hifimeth_pileup.cpp
 int cmd_sample(int argc, char** argv);   // hifimeth_pileup.cpp
@@ -613,6 +614,7 @@ int main(int argc, char** argv) {
     if (cmd == "modstats") return cmd_modstats(argc, argv);
     if (cmd == "pileup") return cmd_pileup(argc, argv);
     if (cmd == "fastats") return cmd_fastats(argc, argv);
+    if (cmd == "thresholds") return cmd_thresholds(argc, argv);
     if (cmd == "corr") return cmd_corr(argc, argv);
     if (cmd == "cov2bed") return cmd_cov2bed(argc, argv);
     if (cmd == "sample") return cmd_sample(argc, argv);

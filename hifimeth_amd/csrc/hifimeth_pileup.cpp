@@ -634,6 +634,26 @@ int cmd_fastats(int argc, char** argv) {
     return 0;
 }
 
+// test seam: the threshold resolver of `pileup` / `eval` on histograms from stdin, in the format of oracle/ref_build's
+// ref_pileup driver (n, then n x 3 x 256 counts -> n lines "cpg chg chh"); tests/golden/pileup_thresholds.json holds the
+// reference's own answers
+int cmd_thresholds(int, char**) {
+    int n = 0;
+    if (scanf("%d", &n) != 1) return EXIT_FAILURE;
+    for (int c = 0; c < n; ++c) {
+        uint64_t bins[3][256];
+        for (auto& b : bins)
+            for (auto& v : b) {
+                unsigned long long x = 0;
+                if (scanf("%llu", &x) != 1) return EXIT_FAILURE;
+                v = x;
+            }
+        uint64_t samples = 0;
+        printf("%d %d %d\n", resolve_threshold(bins[0], &samples), resolve_threshold(bins[1], &samples), resolve_threshold(bins[2], &samples));
+    }
+    return 0;
+}
+
 namespace {
 // s_resolve_scaled_prob_threshold (pileup.cpp:355-436, eval.cpp:213-305): the three thresholds with the reference's messages
 void report_thresholds(const uint64_t* bins, uint8_t thr[3]) {

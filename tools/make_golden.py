@@ -420,6 +420,46 @@ def make_helpers():
         os.remove(f_)
 
 
+def make_pileup_thresholds():
+    """pileup_thresholds.json: the reference's own s_resolve_scaled_prob_threshold (src/app/hifimeth/pileup.cpp:355-436;
+    compiled in place into oracle/_ref/ref_pileup), run on histogram triples that cover its branches: bimodal (the valley is
+    the threshold), too few samples (< 10 000 in the window -> 128), a window narrower than 50 bins, ties for the minimum
+    (the first one wins), counts below 10 at the window's edges, empty histograms, mass only outside [20, 236)."""
+    import subprocess
+    rng = np.random.default_rng(20250220)
+    cases = []
+
+    def bimodal(n, lo_c, hi_c, w=18.0, floor=0):
+        x = np.arange(256)
+        h = n * (0.6 * np.exp(-0.5 * ((x - lo_c) / w) ** 2) + 0.4 * np.exp(-0.5 * ((x - hi_c) / w) ** 2)) + floor
+        return rng.poisson(h).astype(np.int64)
+
+    for _ in range(10):
+        cases.append([bimodal(rng.integers(2000, 60000), rng.integers(5, 60), rng.integers(180, 250), rng.uniform(8, 40),
+                              rng.integers(0, 30)) for _ in range(3)])
+    flat = np.full(256, 100, np.int64)                      # every bin ties: the first bin of the window wins
+    few = bimodal(300, 30, 220, 25.0, 12)                   # window wide enough, fewer than 10 000 samples -> 128
+    narrow = np.zeros(256, np.int64); narrow[100:140] = 5000   # en - st < 50 -> 128
+    edges = np.full(256, 400, np.int64); edges[:40] = 3; edges[200:] = 9; edges[120] = 17; edges[150] = 17  # trimmed edges, tie
+    outside = np.zeros(256, np.int64); outside[:20] = 10 ** 6; outside[236:] = 10 ** 6    # nothing inside the window
+    empty = np.zeros(256, np.int64)
+    big = bimodal(4 * 10 ** 9, 20, 235, 30.0, 1000)         # counts beyond 32 bits
+    step = np.concatenate([np.full(128, 900, np.int64), np.full(128, 50, np.int64)])
+    cases += [[flat, few, narrow], [edges, outside, empty], [big, step, flat[::-1].copy()], [few, few, few]]
+    for _ in range(6):  # random sparse / noisy histograms
+        cases.append([rng.integers(0, rng.integers(2, 400), 256).astype(np.int64) * (rng.random(256) < rng.uniform(0.3, 1.0)) for _ in range(3)])
+    txt = [str(len(cases))]
+    for c in cases:
+        for h in c:
+            txt.append(" ".join(str(int(v)) for v in h))
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_pileup")
+    out = subprocess.run([exe], input="\n".join(txt) + "\n", capture_output=True, text=True, check=True).stdout.split()
+    thr = [[int(out[3 * i + k]) for k in range(3)] for i in range(len(cases))]
+    json.dump(dict(cases=[[[int(v) for v in h] for h in c] for c in cases], thresholds=thr),
+              open(os.path.join(GOLD, "pileup_thresholds.json"), "w"))
+    print(f"pileup_thresholds.json: {len(cases)} histogram triples; thresholds {sorted(set(t for r in thr for t in r))}")
+
+
 if __name__ == "__main__":
     if not O.ref_scan_available():
         raise SystemExit("build oracle/_ref first: make -C oracle")
@@ -428,6 +468,9 @@ if __name__ == "__main__":
         raise SystemExit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "helpers":    # only the cov2bed / corr fixtures
         make_helpers()
+        raise SystemExit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "thresholds":  # only the pileup threshold fixture
+        make_pileup_thresholds()
         raise SystemExit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "chg":        # only the CHG CNN fixture (windows are those of cnn_CpG.npz)
         make_cnn_chg(np.load(os.path.join(GOLD, "cnn_CpG.npz"))["windows"])
@@ -439,3 +482,4 @@ if __name__ == "__main__":
     make_config_goldens()
     make_align()
     make_helpers()
+    make_pileup_thresholds()
