@@ -634,9 +634,8 @@ int cmd_fastats(int argc, char** argv) {
     return 0;
 }
 
-// test seam: the threshold resolver of `pileup` / `eval` on histograms from stdin, in the format of oracle/ref_build's
-// ref_pileup driver (n, then n x 3 x 256 counts -> n lines "cpg chg chh"); tests/golden/pileup_thresholds.json holds the
-// reference's own answers
+// test seam: the threshold resolver of `pileup` / `eval` on histograms from stdin (n, then n x 3 x 256 counts -> n lines
+// "cpg chg chh"); tests/golden/pileup_thresholds.json holds the reference's own answers for the same input format
 int cmd_thresholds(int, char**) {
     int n = 0;
     if (scanf("%d", &n) != 1) return EXIT_FAILURE;
