@@ -3,6 +3,7 @@
 scan.json    <- reference C++ scanner (eval_kmer_features.cpp:67-126) built by oracle/ref_build
 windows.npz  <- reference Python assembler (training/sample_dataset.py:84-139)
 cnn_*.npz    <- reference TorchScript models models/CpG.pt, models/CHH.pt; models/CHG.onnx via torch functional ops
+softmax_ml.json <- reference s_logits_to_methy_probs (mod_batch.cpp:46-64) compiled in place by oracle/ref_build
 """
 import json
 import os
@@ -115,6 +116,31 @@ def test_softmax_ml_byte(oracle):
     p, ml = oracle.softmax(lg)
     assert ml.tolist() == [127, 255, 0, int(255 * p[3])]
     assert abs(p[0] - 0.5) < 1e-7
+
+
+def test_softmax_ml_bytes_match_the_reference_function(oracle):
+    """tests/golden/softmax_ml.json was made by the REFERENCE's own s_logits_to_methy_probs (mod_batch.cpp:46-64, compiled in
+    place: oracle/ref_build/ref_softmax_driver.cpp, tools/make_golden.py softmax): 2 786 logit pairs incl. both sides of every
+    255 * p = k truncation boundary.  The oracle's a10 must give the same byte for every pair (same float arithmetic, same libm)."""
+    g = json.load(open(os.path.join(GOLDEN, "softmax_ml.json")))
+    lg = np.array([[int(h[:8], 16), int(h[8:], 16)] for h in g["logits_hex"]], np.uint32).view(np.float32)
+    p, ml = oracle.softmax(lg)
+    assert ml.tolist() == g["ml"]
+    assert len(set(g["ml"])) == 256
+    # and the float probability is the value the byte was truncated from
+    q = np.minimum((255 * p).astype(np.int32), 255)
+    assert q.tolist() == g["ml"]
+
+
+def test_reference_softmax_build_reproduces_the_fixture():
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "ref_softmax")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_softmax not built (reference absent)")
+    g = json.load(open(os.path.join(GOLDEN, "softmax_ml.json")))
+    txt = str(len(g["ml"])) + "\n" + "\n".join(h[:8] + " " + h[8:] for h in g["logits_hex"]) + "\n"
+    out = subprocess.run([exe], input=txt, capture_output=True, text=True, check=True).stdout.split()
+    assert [int(x) for x in out] == g["ml"]
 
 
 def test_geometry(oracle_models):

@@ -460,6 +460,33 @@ def make_pileup_thresholds():
     print(f"pileup_thresholds.json: {len(cases)} histogram triples; thresholds {sorted(set(t for r in thr for t in r))}")
 
 
+def make_softmax():
+    """softmax_ml.json: the reference's own s_logits_to_methy_probs (src/app/hifimeth/mod_batch.cpp:46-64; compiled in place
+    into oracle/_ref/ref_softmax) on logit pairs: random, equal, far apart, and pairs placed on both sides of every
+    255 * p = k boundary (where the truncation to the ML byte flips)."""
+    import subprocess
+    rng = np.random.default_rng(20250221)
+    v0 = [rng.normal(0, 4, 1500).astype(np.float32)]
+    v1 = [rng.normal(0, 4, 1500).astype(np.float32)]
+    k = np.arange(1, 255, dtype=np.float64)
+    for eps in (-3e-6, -3e-7, 0.0, 3e-7, 3e-6):          # p = k / 255 +- eps: logit difference log(p / (1 - p))
+        pt = np.clip(k / 255.0 + eps, 1e-9, 1 - 1e-9)
+        base = rng.normal(0, 3, len(k))
+        v0.append(base.astype(np.float32))
+        v1.append((base.astype(np.float32).astype(np.float64) + np.log(pt / (1 - pt))).astype(np.float32))
+    ext = np.array([[0, 0], [1, 1], [-7.5, -7.5], [0, 50], [50, 0], [0, 100], [100, 0], [-80, 80], [3e4, -3e4], [0, 5.54], [0, 5.55],
+                    [1e-30, -1e-30], [0, 16.7], [0, 88.0], [0, -88.0], [12.25, 12.25]], np.float32)
+    v0.append(ext[:, 0]); v1.append(ext[:, 1])
+    lg = np.stack([np.concatenate(v0), np.concatenate(v1)], 1).astype(np.float32)
+    txt = str(len(lg)) + "\n" + "\n".join(f"{a:08x} {b:08x}" for a, b in lg.view(np.uint32))
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_softmax")
+    out = subprocess.run([exe], input=txt + "\n", capture_output=True, text=True, check=True).stdout.split()
+    ml = [int(x) for x in out]
+    assert len(ml) == len(lg)
+    json.dump(dict(logits_hex=[f"{a:08x}{b:08x}" for a, b in lg.view(np.uint32)], ml=ml), open(os.path.join(GOLD, "softmax_ml.json"), "w"))
+    print(f"softmax_ml.json: {len(ml)} logit pairs, bytes {min(ml)}..{max(ml)}, {len(set(ml))} distinct")
+
+
 if __name__ == "__main__":
     if not O.ref_scan_available():
         raise SystemExit("build oracle/_ref first: make -C oracle")
@@ -468,6 +495,9 @@ if __name__ == "__main__":
         raise SystemExit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "helpers":    # only the cov2bed / corr fixtures
         make_helpers()
+        raise SystemExit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "softmax":     # only the logits -> ML byte fixture
+        make_softmax()
         raise SystemExit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "thresholds":  # only the pileup threshold fixture
         make_pileup_thresholds()
@@ -483,3 +513,4 @@ if __name__ == "__main__":
     make_align()
     make_helpers()
     make_pileup_thresholds()
+    make_softmax()
