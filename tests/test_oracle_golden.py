@@ -77,6 +77,16 @@ def test_codec_tables(oracle):
     assert oracle.encode_frames(5000) == 255 and oracle.encode_frames(65) == 64 and oracle.encode_frames(195) == 128
 
 
+def test_codec_matches_the_reference_functions(oracle):
+    """tests/golden/codec.json: the reference's own decode table (BamKinetics ctor) and s_encode_signal_value
+    (bam_info.cpp:455-478, 568-576; compiled in place, oracle/ref_build/ref_codec_driver.cpp)"""
+    g = json.load(open(os.path.join(GOLDEN, "codec.json")))
+    assert oracle.codev1_table().tolist() == g["decode"]
+    assert [oracle.encode_frames(s) for s in range(1200)] == g["encode_0_1199"]
+    for s, c in g["encode_big"].items():
+        assert oracle.encode_frames(int(s)) == c
+
+
 def test_u16_kinetics_equal_reencoded_u8(oracle):
     rd = synth_reads(1, seed=3, median_len=1200, sigma=0.05, frac_wide=1.0, frac_missing=0, frac_short=0)[0]
     assert rd.fi.dtype == np.uint16

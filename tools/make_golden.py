@@ -487,6 +487,20 @@ def make_softmax():
     print(f"softmax_ml.json: {len(ml)} logit pairs, bytes {min(ml)}..{max(ml)}, {len(set(ml))} distinct")
 
 
+def make_codec():
+    """codec.json: the reference's own codev1 decode table (BamKinetics ctor, src/corelib/bam_info.cpp:568-576) and lossy
+    u16 -> u8 encoder s_encode_signal_value (:455-478), compiled in place into oracle/_ref/ref_codec."""
+    import subprocess
+    out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_codec")], capture_output=True, text=True, check=True).stdout.splitlines()
+    dec = [int(x) for x in out[0].split()]
+    enc = [int(x) for x in out[1].split()]
+    big = [int(x) for x in out[2].split()]
+    assert len(dec) == 256 and len(enc) == 1200 and len(big) == 3
+    json.dump(dict(decode=dec, encode_0_1199=enc, encode_big={"2000": big[0], "4095": big[1], "65535": big[2]}),
+              open(os.path.join(GOLD, "codec.json"), "w"))
+    print(f"codec.json: decode table 0..{dec[-1]}, encode(0..1199) -> 0..{max(enc)}")
+
+
 if __name__ == "__main__":
     if not O.ref_scan_available():
         raise SystemExit("build oracle/_ref first: make -C oracle")
@@ -495,6 +509,9 @@ if __name__ == "__main__":
         raise SystemExit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "helpers":    # only the cov2bed / corr fixtures
         make_helpers()
+        raise SystemExit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "codec":       # only the kinetics codec fixture
+        make_codec()
         raise SystemExit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "softmax":     # only the logits -> ML byte fixture
         make_softmax()
@@ -514,3 +531,4 @@ if __name__ == "__main__":
     make_helpers()
     make_pileup_thresholds()
     make_softmax()
+    make_codec()
