@@ -593,6 +593,27 @@ int cmd_modstats(int argc, char** argv) {
     return 0;
 }
 
+// test seam: the MM/ML parser's output per record, "n" then n lines "qoff strand unmod_base code prob" (the format of the
+// reference-parser driver behind tests/golden/modparse.json)
+int cmd_modlist(int argc, char** argv) {
+    if (argc != 3) { usage(); return EXIT_FAILURE; }
+    BgzfReader in(argv[2], 2);
+    BamHeader h;
+    std::string err;
+    if (!in.ok() || !read_header(in, h, err)) { fprintf(stderr, "%s%s\n", in.error().c_str(), err.c_str()); return EXIT_FAILURE; }
+    BamRecord r;
+    std::vector<BaseMod> mods;
+    uint64_t reads = 0;
+    while (read_record(in, r, err)) {
+        ++reads;
+        if (!parse_mods(r, mods, err)) { fprintf(stderr, "read %llu: %s\n", (unsigned long long)reads - 1, err.c_str()); return EXIT_FAILURE; }
+        printf("%zu\n", mods.size());
+        for (const BaseMod& m : mods) printf("%d %d %c %c %d\n", m.qoff, (int)m.strand, m.unmod_base, m.code, (int)m.prob);
+    }
+    if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return EXIT_FAILURE; }
+    return 0;
+}
+
 }  // namespace
 
 int cmd_pileup(int argc, char** argv);   // hifimeth_pileup.cpp
@@ -615,6 +636,7 @@ int main(int argc, char** argv) {
     if (cmd == "pileup") return cmd_pileup(argc, argv);
     if (cmd == "fastats") return cmd_fastats(argc, argv);
     if (cmd == "thresholds") return cmd_thresholds(argc, argv);
+    if (cmd == "modlist") return cmd_modlist(argc, argv);
     if (cmd == "corr") return cmd_corr(argc, argv);
     if (cmd == "cov2bed") return cmd_cov2bed(argc, argv);
     if (cmd == "sample") return cmd_sample(argc, argv);

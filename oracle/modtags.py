@@ -2,7 +2,12 @@
 
 Follows src/corelib/build_mod_bam.cpp:125-248: MM:Z = "C+m" {",d"} ";" "G-m" {",d"} ";" where d is the number of
 unmodified-candidate bases (C on the forward strand, resp. G) skipped since the previous call; ML:B:C = forward calls
-then reverse calls; MN = l_qseq.  `fwd_seq` is the forward-strand sequence (bam_info.cpp:224-233)."""
+then reverse calls; MN = l_qseq.  `fwd_seq` is the forward-strand sequence (bam_info.cpp:224-233).
+
+Pin status: the MM / ML strings these rules write are mapped back to exactly the calls they were written from by the
+reference's own parser core (s_parse_one_mod_list, compiled in place into oracle/_ref/ref_modparse; asserted when
+tests/golden/modparse.json is made) and equal hand-worked strings (modtags_known_answers.json); MN and the order / removal
+of tags in the record follow build_mod_bam.cpp by reading only (its code calls the htslib library inline)."""
 import numpy as np
 
 

@@ -5,9 +5,10 @@ Pure-Python loops, sized for test inputs.  Each function cites the reference lin
 Pin status: `cigar_to_alignment`, `map_info` and `chh_mapped_samples` are checked against the reference's own code
 (oracle/ref_build builds BamMapInfo::init + 5mc_motif_finder.cpp into oracle/_ref/ref_align; fixtures in
 tests/golden/align.json); `resolve_threshold` against the reference's own s_resolve_scaled_prob_threshold (pileup.cpp is
-compiled in place into oracle/_ref/ref_pileup; fixtures in tests/golden/pileup_thresholds.json).  The MM/ML parser
-(bam_mod_parser.cpp) and the record/count/BED stages of pileup.cpp call htslib functions whose library is not in this
-image, so those stages are a restatement by reading: PARITY UNPINNED.
+compiled in place into oracle/_ref/ref_pileup; fixtures in tests/golden/pileup_thresholds.json); `parse_mods` against the
+reference's own parser core s_parse_one_mod_list (bam_mod_parser.cpp compiled in place into oracle/_ref/ref_modparse;
+fixtures in tests/golden/modparse.json).  The record/count/BED stages of pileup.cpp are inline in a function that calls the
+htslib library, which is not in this image, so those stages are a restatement by reading: PARITY UNPINNED.
 `cov_to_bed` is pinned against the reference's whole `cov2bed` subcommand (oracle/_ref/ref_tools, tests/golden/helpers.json).
 
 Where the reference's output depends on thread timing (two motif classes landing on one locus, see `count`), the

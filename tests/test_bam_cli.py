@@ -254,6 +254,70 @@ def test_mm_ml_parser_roundtrip_and_histograms(tmp_path, oracle, oracle_models):
     assert st0["calls"] == 0 and st0["reads_with_mods"] == 0 and st0["CpG"]["threshold"] == 128
 
 
+def _modparse_golden():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "modparse.json")))["records"]
+
+
+def test_mm_ml_parsers_match_the_reference_parser(tmp_path):
+    """tests/golden/modparse.json: the REFERENCE's own parser core (s_parse_one_mod_list, bam_mod_parser.cpp:136-229, compiled
+    in place: oracle/ref_build/ref_modparse_driver.cpp) on our writer's strings (both strands, a flag-16 read), the hand-worked
+    known answers and other accepted dialects.  The oracle's parser, the host mirror and the CLI's C++ parser must list the
+    same (qoff, strand, base, code, probability) in the same order."""
+    from hifimeth_amd.pileup import parse_mods
+    from hifimeth_amd.synth import read_from_ascii
+    from oracle import pileup_oracle as P
+    recs = _modparse_golden()
+    assert len(recs) >= 15 and sum(len(r["mods"]) for r in recs) > 2000
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    reads = []
+    for i, r in enumerate(recs):
+        want = [tuple(m) for m in r["mods"]]
+        seq = r["seq"].encode()
+        fwd = (seq.translate(comp)[::-1] if r["flag"] & 16 else seq).decode()
+        assert [tuple(m) for m in P.parse_mods(fwd, r["mm"], r["ml"])] == want, i
+        got = parse_mods(r["seq"], r["flag"], r["mm"], np.array(r["ml"], np.uint8))
+        assert [(int(m["qoff"]), int(m["strand"]), m["unmod_base"].decode(), m["code"].decode(), int(m["prob"])) for m in got] == want, i
+        k = np.zeros(len(seq), np.uint8)
+        reads.append(read_from_ascii(seq, k, k, k, k, flag=r["flag"], name=f"r{i}"))
+    src = str(tmp_path / "mods.bam")
+    bamutil.reads_to_bam(src, reads, extra_aux=lambda i, rd: bamutil.aux_Z("MM", recs[i]["mm"]) + bamutil.aux_B("ML", np.array(recs[i]["ml"], np.uint8)))
+    out = subprocess.run([CLI, "modlist", src], capture_output=True, text=True, check=True).stdout.split("\n")
+    li = 0
+    for i, r in enumerate(recs):
+        n = int(out[li]); li += 1
+        got = []
+        for _ in range(n):
+            q, st, ub, code, pr = out[li].split(); li += 1
+            got.append((int(q), int(st), ub, code, int(pr)))
+        assert got == [tuple(m) for m in r["mods"]], i
+
+
+def test_tag_writer_output_is_what_the_reference_parser_reads_back(tmp_path):
+    """the fixture's first records carry the calls their MM/ML were written from, and the reference's parser maps those strings
+    back to exactly these calls (asserted when the fixture was made): the product writer must produce the same strings."""
+    from hifimeth_amd.synth import read_from_ascii
+    recs = [r for r in _modparse_golden() if "calls" in r]
+    assert len(recs) >= 6
+    reads, calls = [], []
+    for i, r in enumerate(recs):
+        seq = r["seq"].encode()
+        k = np.zeros(len(seq), np.uint8)
+        reads.append(read_from_ascii(seq, k, k, k, k, flag=r["flag"], name=f"w{i}"))
+        rec = np.zeros(len(r["calls"]), CALL_DTYPE)
+        for j, (q, st, mlb) in enumerate(r["calls"]):
+            rec[j] = (i, q, st, 0, mlb, 0, mlb / 255.0)
+        calls.append(rec)
+    src, dst, cb = str(tmp_path / "in.bam"), str(tmp_path / "out.bam"), str(tmp_path / "calls.bin")
+    bamutil.reads_to_bam(src, reads)
+    np.concatenate(calls).tofile(cb)
+    subprocess.check_call([CLI, "tagtest", src, cb, dst])
+    _, out = bamutil.read_bam(dst)
+    for r, rec in zip(recs, out):
+        d = {t[0]: t for t in bamutil.parse_aux(rec["aux"])}
+        assert d["MM"][2] == r["mm"] and d["ML"][2].tolist() == r["ml"]
+
+
 def test_threshold_rule_known_answers():
     from oracle.modtags import resolve_threshold
     flat = [1000] * 256

@@ -501,6 +501,57 @@ def make_codec():
     print(f"codec.json: decode table 0..{dec[-1]}, encode(0..1199) -> 0..{max(enc)}")
 
 
+def make_modparse():
+    """modparse.json: the reference's own MM/ML parser core (s_parse_one_mod_list, src/corelib/bam_mod_parser.cpp:136-229;
+    compiled in place into oracle/_ref/ref_modparse) on (flag, stored SEQ, MM, ML) records:
+      * the MM/ML strings our WRITER rules produce for oracle calls on synthetic reads (both strands, a flag-16 read) -- the
+        reference parser must give back exactly those calls (asserted here), which pins the writer's semantics to it;
+      * the hand-worked known answers of modtags_known_answers.json;
+      * other dialects the parser accepts: '?' / '.' flags, two codes per position, several lists, other bases."""
+    import subprocess
+    from oracle.modtags import expected_tags
+    recs = []
+    reads = synth_reads(6, seed=41, median_len=1500, sigma=0.2, frac_short=0, frac_missing=0, frac_wide=0.3)
+    reads[1].flag = 16
+    reads[4].flag = 16
+    models = [O.Model(os.path.join(ROOT, "hifimeth_amd", "weights", c + ".hmw")) for c in ("CpG", "CHG", "CHH")]
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    for rd in reads:
+        c = O.call_read(models, 7, rd)
+        order = np.lexsort((c["qoff"], c["strand"]))
+        fwd = O.decode(rd)
+        tags = expected_tags(fwd, c["qoff"][order], c["strand"][order], c["ml"][order])
+        recs.append(dict(flag=int(rd.flag), seq=rd.ascii().decode(), mm=tags["MM"], ml=[int(v) for v in tags["ML"]],
+                         calls=[[int(q), int(s), int(m)] for q, s, m in zip(c["qoff"][order], c["strand"][order], c["ml"][order])]))
+    for k in json.load(open(os.path.join(GOLD, "modtags_known_answers.json")))["cases"]:
+        recs.append(dict(flag=k["flag"], seq=k["stored_seq"], mm=k["MM"], ml=k["ML"], calls=[list(x) for x in k["calls"]]))
+    s0 = reads[0].ascii().decode()
+    # (no ChEBI case: the reference's numeric-code path cannot succeed -- s_chebi_to_iupac_code:44 compares the ',' behind the
+    #  number with the list's LENGTH, and where that passes the caller asserts on the character behind the ',' it skipped
+    #  (bam_mod_parser.cpp:183); our parsers accept ChEBI codes, a superset that no reference-written file exercises)
+    recs += [dict(flag=0, seq=s0, mm="C+m?,0;C+h.,0;", ml=[9, 8]),
+             dict(flag=0, seq=s0, mm="C+mh,2;", ml=[11, 12]), dict(flag=16, seq=s0, mm="G-m,3,0,0;C+m,1;", ml=[1, 2, 3, 4]),
+             dict(flag=0, seq=s0, mm="A+a,0,5;T-a,2;", ml=[5, 6, 7])]
+    txt = [str(len(recs))]
+    for r in recs:
+        txt.append(f"{r['flag']} {r['seq']} {r['mm']} {len(r['ml'])} " + " ".join(str(v) for v in r["ml"]))
+    out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_modparse")], input="\n".join(txt) + "\n", capture_output=True,
+                         text=True, check=True).stdout.split("\n")
+    li = 0
+    for r in recs:
+        n = int(out[li]); li += 1
+        mods = []
+        for _ in range(n):
+            q, st, ub, code, pr = out[li].split(); li += 1
+            mods.append([int(q), int(st), ub, code, int(pr)])
+        r["mods"] = mods
+        if "calls" in r:  # the writer's strings mean exactly the calls they were written from, by the reference's own parser
+            got = sorted((m[0], m[1], m[4]) for m in mods)
+            assert got == sorted(tuple(x) for x in r["calls"]), "writer / reference parser disagree"
+    json.dump(dict(records=recs), open(os.path.join(GOLD, "modparse.json"), "w"))
+    print(f"modparse.json: {len(recs)} records, {sum(len(r['mods']) for r in recs)} mods parsed by the reference")
+
+
 if __name__ == "__main__":
     if not O.ref_scan_available():
         raise SystemExit("build oracle/_ref first: make -C oracle")
@@ -509,6 +560,9 @@ if __name__ == "__main__":
         raise SystemExit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "helpers":    # only the cov2bed / corr fixtures
         make_helpers()
+        raise SystemExit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "modparse":    # only the MM/ML parser fixture
+        make_modparse()
         raise SystemExit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "codec":       # only the kinetics codec fixture
         make_codec()
@@ -532,3 +586,4 @@ if __name__ == "__main__":
     make_pileup_thresholds()
     make_softmax()
     make_codec()
+    make_modparse()
