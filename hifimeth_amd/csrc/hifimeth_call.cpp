@@ -11,6 +11,9 @@
 //     hifimeth-hip pileup [OPTIONS] REF.fa MOD.bam PREFIX   (hifimeth_pileup.cpp)
 //     hifimeth-hip corr [-c N] A.cov.bed B.cov.bed          (Pearson r of two pileup outputs, hifimeth_pileup.cpp)
 //     hifimeth-hip modstats IN.bam                    (MM/ML parser + per-context histograms + adaptive thresholds)
+//     hifimeth-hip modlist IN.bam                     (the MM/ML parser's output per record: test seam against the
+//                                                      reference parser's fixture, tests/golden/modparse.json)
+//     hifimeth-hip thresholds < HISTOGRAMS            (the threshold resolver alone: tests/golden/pileup_thresholds.json)
 #include <unistd.h>
 
 #include <algorithm>
