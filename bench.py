@@ -14,7 +14,7 @@ only the synthesis of the reads (the stand-in for BAM decode) happens before it.
 slabs (reads are independent: no data-path collective, weak scaling); `value` is the whole-job sites/s = sum of sites
 over ranks / max time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-extras] [--no-e2e] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -56,8 +56,9 @@ def host_cores():
     return n
 
 
-def cpu_baseline(reads, gpu_calls=None, budget_s=15.0, tol=1e-4):
+def cpu_baseline(sample, gpu_calls=None, budget_s=25.0, tol=1e-4, what=""):
     """The CPU oracle (port of the reference path) timed on this node's host cores, bounded sample.
+    `sample`: (read id in the slab, read) pairs; `gpu_calls`: {read id: the GPU's records of that read}.
     The oracle's results for that sample double as an in-run parity check of the GPU calls."""
     from oracle import hm_oracle as O
     O.build()
@@ -68,7 +69,7 @@ def cpu_baseline(reads, gpu_calls=None, budget_s=15.0, tol=1e-4):
     nreads = 0
     worst, nml, ncheck = 0.0, 0, 0
     deltas = []
-    for rid, rd in enumerate(reads):
+    for rid, rd in sample:
         if not rd.has_kinetics() or rd.l_qseq < 1000:
             continue
         t1 = time.perf_counter()
@@ -77,7 +78,7 @@ def cpu_baseline(reads, gpu_calls=None, budget_s=15.0, tol=1e-4):
         sites += len(want["qoff"])
         nreads += 1
         if gpu_calls is not None:  # untimed: compare with the GPU's calls for the same read
-            got = gpu_calls[gpu_calls["read_id"] == rid]
+            got = gpu_calls[rid]
             order = np.lexsort((want["qoff"], want["strand"]))
             assert len(got) == len(order) and np.array_equal(got["qoff"], want["qoff"][order]), "site lists differ"
             d = np.abs(got["p"] - want["p"][order])
@@ -88,7 +89,7 @@ def cpu_baseline(reads, gpu_calls=None, budget_s=15.0, tol=1e-4):
         if spent > budget_s:
             break
     out = {"value": sites / spent, "unit": "sites/s", "cores": cores, "kind": "port",
-           "sample": f"first {nreads} reads of the rank-0 slab 0 ({sites} sites, all contexts), "
+           "sample": f"{nreads} reads of the rank-0 slab 0 {what}({sites} sites, all contexts), "
                      f"oracle/hm_oracle.c fp32 ({O.variant} build), OpenMP over sites on all {cores} cores this job is "
                      f"granted ({os.cpu_count()} online), {spent:.1f} s",
            "extrapolated_48_threads": sites / spent * 48 / cores,
@@ -97,10 +98,106 @@ def cpu_baseline(reads, gpu_calls=None, budget_s=15.0, tol=1e-4):
     parity = None
     if gpu_calls is not None:
         alld = np.concatenate(deltas) if deltas else np.zeros(1)
-        parity = {"sites_checked": ncheck, "max_abs_dp_vs_oracle": worst, "mean_abs_dp": float(alld.mean()),
+        parity = {"sample": what.strip() or "synchronous call", "sites_checked": ncheck, "max_abs_dp_vs_oracle": worst, "mean_abs_dp": float(alld.mean()),
                   "p999_abs_dp": float(np.quantile(alld, 0.999)), "ml_bytes_off_by_1lsb": nml, "tolerance": tol,
                   "frac_above_1e-4": float((alld > 1e-4).mean()), "frac_above_1e-3": float((alld > 1e-3).mean())}
     return out, parity
+
+
+GROUP_BASES = 2 << 20   # engine default `group_bases`: reads per trunk group (hm_engine.cpp, stage_read)
+
+
+def trunk_groups(reads):
+    """Group index of every accepted read of a slab, by the engine's own rule: a new group starts once the current one holds
+    GROUP_BASES bases (hm_engine.cpp: stage_read).  -1 for reads the engine passes through."""
+    g, held, out = -1, GROUP_BASES, []
+    for r in reads:
+        if not r.has_kinetics() or r.l_qseq < 1000:
+            out.append(-1)
+            continue
+        if held >= GROUP_BASES:
+            g, held = g + 1, 0
+        held += r.l_qseq
+        out.append(g)
+    return out
+
+
+def parity_sample(reads, per_group=32):
+    """Read ids of the oracle sample of a streamed slab: the first reads of trunk group 0, reads from the middle group and
+    the LAST reads of the last group -- the map buffers are reused group after group, so a wrong map offset or a buffer
+    reused one launch early would show in the later groups only."""
+    grp = trunk_groups(reads)
+    ng = max(grp) + 1
+    if ng <= 0:
+        return [], 0
+    picks = []
+    for g in sorted({0, ng // 2, ng - 1}):
+        members = [i for i, x in enumerate(grp) if x == g]
+        picks.append(members[-per_group:][::-1] if g == ng - 1 and ng > 1 else members[:per_group])
+    # interleaved, so that a CPU time budget that runs out early has still seen every group
+    ids = [p[k] for k in range(per_group) for p in picks if k < len(p)]
+    return list(dict.fromkeys(ids)), ng
+
+
+def quoted_traffic(tm, launches, sites):
+    """roofline.traffic for the trunk kernel.  HBM bytes come from PMC counters, which need rocprofv3 passes of their own
+    (one counter group per run) and cannot be read from inside this process: the figure is QUOTED from the kept pass of
+    this round (profiles/r03_traffic.json, written by tools/pmc_derive.py from a run of this same command: HBM-side bytes per
+    view position of trunk2_kernel, gfx950 corrections applied) and scaled to this run's positions per launch."""
+    alg = 28.0 * sites / max(1, launches)   # SURVEY.md 8(d): ~16 B of raw input + 12 B of result per site
+    out = {"traffic": None, "algorithmic_bytes": alg,
+           "traffic_note": "HBM bytes need separate rocprofv3 --pmc passes; profiles/r03_traffic.json absent"}
+    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    try:
+        q = json.load(open(path))["trunk2_kernel"]
+        per_pos = {0: q["k11"], 1: q["k11"], 2: q["k13"]}
+        tot = sum(tm["trunk_positions"][c] * (per_pos[c]["read_B_per_position"] + per_pos[c]["write_B_per_position"]) for c in range(3))
+        out.update({"traffic": tot / max(1, launches), "traffic_over_algorithmic": tot / max(1, launches) / alg,
+                    "traffic_note": "QUOTED: HBM-side bytes per launch = this run's view positions per launch x the bytes per "
+                                    "position measured by rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections) "
+                                    "on this command; the maps E1..E4 the design parks in HBM are what exceeds the algorithmic bytes",
+                    "quoted": "profiles/r03_traffic.json"})
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
+
+
+def end_to_end(slabs, n_reads, ctx="cpg,chg,chh"):
+    """`hifimeth-hip call IN.bam OUT.bam` with the reference's default flags (mod_options.cpp:10-17) on a synthetic BAM of
+    n_reads reads: BGZF inflate -> parse -> stage -> GPU -> MM/ML tags -> deflate, engine start-up included -- the quantity
+    the reference's one published figure is about (README.md:31: wall-clock of the whole command)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from hifimeth_amd.synth import write_unaligned_bam
+    cli = os.path.join(ROOT, "hifimeth_amd", "bin", "hifimeth-hip")
+    if not os.path.exists(cli):
+        return {"error": "hifimeth_amd/bin/hifimeth-hip is not built"}
+    reads = [r for s in slabs for r in s][:n_reads]
+    tmp = tempfile.mkdtemp(prefix="hm_e2e_")
+    try:
+        src, dst = os.path.join(tmp, "in.bam"), os.path.join(tmp, "out.bam")
+        t0 = time.perf_counter()
+        write_unaligned_bam(src, reads, level=1, threads=host_cores())
+        t_build = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        p = subprocess.run([cli, "call", "-c", ctx, src, dst], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            return {"error": f"exit {p.returncode}: {p.stderr[-300:]}"}
+        st = {}
+        for line in p.stderr.splitlines():
+            if "##" in line and ":" in line:
+                k, v = line.split("##", 1)[1].split(":", 1)
+                st[k.strip()] = v.strip()
+        sites = sum(int(st.get(f"{c} samples", "0")) for c in ("CpG", "CHG", "CHH"))
+        return {"value": sites / wall, "unit": "sites/s", "wall_s": wall, "reads": len(reads), "bases": int(st.get("Bases", "0")),
+                "sites": sites, "bam_in_MB": os.path.getsize(src) / 1e6, "bam_out_MB": os.path.getsize(dst) / 1e6,
+                "host_threads": host_cores(), "flags": "defaults (-b 10000, -l 1000, all contexts, -z 6)",
+                "command": "hifimeth-hip call IN.bam OUT.bam", "bam_build_s": t_build,
+                "note": "whole command incl. process and engine start-up; BGZF level-1 input, level-6 output"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def make_slabs(n, reads, seed):
@@ -110,10 +207,11 @@ def make_slabs(n, reads, seed):
         return list(ex.map(lambda i: synth_slab(reads, seed=seed + 7919 * i, gc=0.36), range(n)))
 
 
-def stream(mc, slabs, order):
+def stream(mc, slabs, order, keep=None):
     """Runs slabs[order[0]], slabs[order[1]], ... through the batch pipeline; returns the sites per context.
     `slabs` hold ReadBlocks (descriptors = pointers to the reads' SEQ / kinetics arrays, what a BAM decoder hands over):
-    a step stages its slab with ONE hm_batch_submit_reads call, whose copies into the pinned slab run on a few host threads."""
+    a step stages its slab with ONE hm_batch_submit_reads call, whose copies into the pinned slab run on a few host threads.
+    keep = (read ids, dict): the streamed records of those reads of the FIRST slab are copied into the dict."""
     sites = [0, 0, 0]
     calls_seen = 0
 
@@ -122,6 +220,11 @@ def stream(mc, slabs, order):
         for c in range(3):
             sites[c] += batch.num_sites(c)
         calls_seen += len(calls)  # the records are on the host here (pinned view of the packed D2H)
+        if keep is not None and k == 0:   # records are ordered by read: two binary searches per wanted read
+            rid = calls["read_id"]
+            for i in keep[0]:
+                lo, hi = np.searchsorted(rid, [i, i + 1])
+                keep[1][i] = calls[lo:hi].copy()
 
     mc.stream((slabs[i] for i in order), on_batch=on_batch)
     assert calls_seen == sum(sites)
@@ -133,10 +236,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=5000, help="reads per slab = per step (~15 kb each)")
+    ap.add_argument("--reads", type=int, default=11600,
+                    help="reads per slab = per step (~15 kb each); default: 20 steps cover BASELINE.json configs[2] (~1.1 G sites)")
     ap.add_argument("--pool", type=int, default=6, help="distinct slabs synthesised up front; steps cycle through them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (fp32 mode, resident slab, windows)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI run (BAM in -> BAM out, default flags)")
+    ap.add_argument("--e2e-reads", type=int, default=24000, help="reads of the synthetic BAM of the end-to-end run (24000 ~ 1.26 GB)")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1, 2, 3],
                     help="CNN arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA, 2 = fp16 weights in "
                          "conv6..conv8 (holds the 1e-3 bar of configs[4]), 3 = fp16 weights in conv2..conv8 (misses it)")
@@ -175,8 +281,14 @@ def main():
 
     order_w = [i % n_pool for i in range(args.warmup)]
     order_t = [(args.warmup + i) % n_pool for i in range(args.steps)]
+    # the oracle sample: reads of slab 0 from its first, a middle and its last trunk group; their records are taken from the
+    # STREAMED run of that slab (warm-up step 0: same pipeline, same multi-group launches as the timed steps)
+    want_parity = rank == 0 and world == 1 and not args.no_cpu_baseline
+    sample_ids, n_groups = parity_sample(slabs[0]) if want_parity else ([], 0)
+    streamed = {}
+    keep = (sample_ids, streamed) if sample_ids else None
     if order_w:
-        stream(mc, blocks, order_w)   # untimed: buffers grow to their steady-state size here
+        stream(mc, blocks, order_w, keep=keep)   # untimed: buffers grow to their steady-state size here
     mc.timing(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -190,9 +302,8 @@ def main():
     sites_all, dt_max = hmdist.job_throughput(dist, sites_job, dt, device="cuda" if on_gpu_collectives else "cpu")
 
     extras = {}
-    gpu_calls = None
-    if rank == 0 and world == 1 and args.no_extras and not args.no_cpu_baseline:
-        gpu_calls = mc.call(slabs[0][:96]).copy()   # untimed: the sample the CPU oracle is timed and compared on
+    if keep is not None and not streamed:
+        stream(mc, blocks, [0], keep=keep)   # --warmup 0: the sample's records from an extra, untimed streamed run of slab 0
     if rank == 0 and world == 1 and not args.no_extras:
         # ---- secondary measurements, all OUTSIDE the timed region -----------------------------------------------
         # (a) the same slab resident in HBM, re-run without staging / copies: the kernel-path rate of round 1
@@ -226,8 +337,6 @@ def main():
                     "algorithmic_bytes_per_site": per_site}
             feat["frac"] = feat["achieved"] / feat["peak"]
             extras["feature_extraction"] = feat
-        if not args.no_cpu_baseline:
-            gpu_calls = mc.fetch().copy()
         mc.clear()
         # (c) strict-fp32 arithmetic (v_mfma_f32_16x16x4_f32), streamed the same way over fewer slabs
         if args.precision == 1:
@@ -284,13 +393,14 @@ def main():
                     "avg_launch_ms": trunk_ms / launches, "launches": launches,
                     "executed": executed, "frac_executed": executed / peak,
                     "algorithmic_flops_per_site": {"CpG": 2 * MAC_FRONT[0], "CHG": 2 * MAC_FRONT[1], "CHH": 2 * MAC_FRONT[2]},
+                    "utilisation": executed / peak,
                     "positions_per_site": sum(tm["trunk_positions"]) / max(1, sites_job),
-                    "traffic": None,
-                    "traffic_note": "HBM bytes need separate rocprofv3 --pmc passes; see profiles/ for the per-launch figures",
                     "kernel": "trunk2_kernel (feature rows + bn0 + conv1..conv4 as dense a-trous maps over every read position; streaming form: "
                               "4 waves, a layer's weights resident in registers, positions streamed in tile groups; "
                               "v_mfma_f32_16x16x32_f16 split-half x3, fp32 accumulate); `achieved` = the reference's conv1..conv4 "
-                              "FLOPs for the sites served / kernel time, `executed` = MFMA FLOPs issued / kernel time"}
+                              "FLOPs for the sites served / kernel time, `executed` = MFMA FLOPs issued / kernel time; "
+                              "`utilisation` = executed / peak is the hardware figure, `frac` credits the work the dense form avoids"}
+            roof.update(quoted_traffic(tm, launches, sites_job))
         else:
             front_launches = sum(tm["front_launches"])
             achieved = flop_front_sites(tm["front_sites"]) / (front_ms * 1e-3) / 1e12 if front_ms > 0 else 0.0
@@ -300,12 +410,13 @@ def main():
             products = exec_macs / max(1.0, sum(MAC_FRONT[c] * tm["front_sites"][c] for c in range(3))) if split else 1.0
             roof = {"bound": "mfma", "unit": "TFLOP/s", "achieved": achieved, "peak": peak, "frac": achieved / peak,
                     "avg_launch_ms": front_ms / front_launches if front_launches else None, "launches": front_launches,
-                    "traffic": None,
+                    "traffic": None, "utilisation": None,
                     "traffic_note": "HBM bytes need separate rocprofv3 --pmc passes; see profiles/ for the per-launch figures",
                     "kernel": ("front_kernel_h (window+bn0+conv1..conv4 per site, v_mfma_f32_16x16x32_f16 x3 split-half, fp32 accumulate)"
                                if split else "front_kernel (window+bn0+conv1..conv4 per site, v_mfma_f32_16x16x4_f32)")}
             if split:
-                roof.update(executed=products * achieved, frac_executed=products * achieved / peak, products_per_mac=products,
+                roof.update(executed=products * achieved, frac_executed=products * achieved / peak, utilisation=products * achieved / peak,
+                            products_per_mac=products,
                             vs_fp32_mfma_peak=achieved / PEAK_FP32_MFMA_TFLOPS)
         gpu_ms = {k: tm[k] for k in ("prep_ms", "scan_ms", "emit_ms", "pack_ms", "empty_ms")}
         gpu_ms["front_ms"] = front_ms
@@ -344,8 +455,15 @@ def main():
             "effective_tflops_all_layers": sum(2.0 * MAC_TOTAL[c] * sites_ctx[c] for c in range(3)) / dt_max / 1e12,
         }
         out.update(extras)
-        if world == 1 and not args.no_cpu_baseline and gpu_calls is not None:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(slabs[0][:96], gpu_calls, tol=1e-4 if args.precision <= 1 else 1e-3)
+        if world == 1 and not args.no_extras and not args.no_e2e:
+            mc.close()   # the CLI is a process of its own on the same device
+            out["end_to_end"] = end_to_end(slabs, args.e2e_reads)
+        if want_parity and streamed:
+            what = (f"(records taken from the STREAMED run of that slab: reads of trunk groups 0, {n_groups // 2} and {n_groups - 1} "
+                    f"of its {n_groups} groups per context) ")
+            out["cpu_baseline"], out["parity"] = cpu_baseline([(i, slabs[0][i]) for i in sample_ids], streamed,
+                                                              tol=1e-4 if args.precision <= 1 else 1e-3, what=what)
+            out["parity"]["trunk_groups_in_slab"] = n_groups
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             # external sanity bound, DERIVED not measured: the reference README's "~2 hours on 48
             # CPU threads" for 30x Arabidopsis, ~1.1e9 sites => ~1.5e5 sites/s; the north-star asks for >= 30x of it

@@ -82,6 +82,7 @@ def lib():
         "hm_batch_begin": (vp, [vp]),
         "hm_batch_submit_read": (C.c_int, [vp, i32, i32, i32, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int]),
         "hm_batch_submit_reads": (i64, [vp, vp, i64, C.c_int, vp]),
+        "hm_trunk_mask_for_reads": (C.c_int, [vp, i64, C.c_int]),
         "hm_batch_staged_bases": (i64, [vp]),
         "hm_batch_enqueue": (C.c_int, [vp]),
         "hm_batch_done": (C.c_int, [vp]),

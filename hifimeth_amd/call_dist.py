@@ -7,7 +7,8 @@ Every read is independent (reference mod_main.cpp:180-212), so `call` needs no d
 native front end (`hifimeth-hip call -R r/N -d <local gpu>`) on ITS byte range of the input -- it inflates, stages and calls
 only its own reads -- and writes out.bam.shard<r>; after a barrier rank 0 joins the shards in rank order, which is input
 order (the order the reference writes in: mod_main.cpp:352-362).  The native program runs as a CHILD process of the rank
-(the rank itself only needs torch.distributed for the barrier), never via exec.
+(the rank itself only needs torch.distributed for a CPU barrier -- gloo unless HM_DIST_BACKEND says otherwise -- and never
+touches the GPU), never via exec.
 `--copy` replaces `call` by `bamcopy` (decode + re-encode, no GPU): the sharding / merge logic on a CPU-only box.
 """
 from __future__ import annotations
@@ -29,6 +30,10 @@ def run(argv, backend: str | None = None) -> int:
         return 2
     out = argv[-1]
     rank, local_rank, world = D.env_world()
+    # The ranks only exchange a failure flag (which doubles as the barrier before the merge): a CPU collective.  gloo
+    # keeps this process off the GPU altogether -- the child that does the work owns the device -- and works on any box;
+    # an explicit "nccl" is honoured (the flag then lives on this rank's device).
+    backend = backend or "gloo"
     dist = D.init_process_group(backend)
     rc = 0
     try:
@@ -43,10 +48,15 @@ def run(argv, backend: str | None = None) -> int:
             except Exception:  # noqa: BLE001
                 pass
             cmd = [CLI, "call"] + argv[:-2] + shard + ["-d", str(local_rank % ndev)] + argv[-2:]
-        rc = subprocess.call(cmd)
+        try:
+            rc = subprocess.call(cmd)
+        except OSError as ex:   # e.g. the native front end is missing: every rank must still reach the collective below
+            print(f"[call_dist] rank {rank}: cannot run {cmd[0]}: {ex}", file=sys.stderr)
+            rc = 127
         if dist is not None:
             import torch
-            flag = torch.tensor([rc != 0], dtype=torch.int32)
+            dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+            flag = torch.tensor([rc != 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)   # doubles as the barrier before the merge
             rc = int(flag.item()) or rc
         if rc == 0 and rank == 0 and world > 1:

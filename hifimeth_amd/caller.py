@@ -235,6 +235,15 @@ class MethylationCaller:
         return d
 
 
+def trunk_mask_for_reads(block: "ReadBlock", ctx_mask: int = 7) -> int:
+    """hm_trunk_mask_for_reads: the per-context kernel-path choice of engine option trunk = 2 for a sample of reads (host
+    only).  Pass the result to set_option("trunk_mask", m) on every engine that shares one input."""
+    rc = _lib.lib().hm_trunk_mask_for_reads(block.desc.ctypes.data_as(C.c_void_p), len(block.desc), ctx_mask)
+    if rc < 0:
+        raise HifimethError(f"hm_trunk_mask_for_reads failed ({rc})")
+    return rc
+
+
 class ReadBlock:
     """Descriptors (hm_read_t) of a list of reads: what a BAM decoder hands to the engine.  Keeps the arrays alive."""
 

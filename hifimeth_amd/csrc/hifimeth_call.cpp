@@ -1,6 +1,8 @@
 // hifimeth_call.cpp -- `hifimeth-hip call`: BAM in -> GPU 5mC calling -> BAM out with MM/ML/MN tags.
 // Keeps the reference's `hifimeth call` surface (src/app/hifimeth/mod_options.cpp:61-181, mod_main.cpp:303-412):
 //     hifimeth-hip call [-m dir] [-l 1000] [-s 32] [-b 10000] [-k] [-c cpg,chg,chh] [-t N] [-d 0,1,..] BAM MOD-BAM
+// -b keeps the reference's meaning and default (reads per outer batch); it does NOT set the granularity of the GPU pipeline:
+// batches are cut into engine slabs of <= 12 Mi bases (-S), so the default flags run the pipeline at full depth.
 // Reads keep their input order; reads shorter than -l or without complete kinetics are passed through with the
 // kinetics / old MM / ML tags stripped, exactly as the reference does.
 // Two extra sub-commands need no GPU and exist for the CPU test-suite:
@@ -14,6 +16,7 @@
 //     hifimeth-hip modlist IN.bam                     (the MM/ML parser's output per record: test seam against the
 //                                                      reference parser's fixture, tests/golden/modparse.json)
 //     hifimeth-hip thresholds < HISTOGRAMS            (the threshold resolver alone: tests/golden/pileup_thresholds.json)
+#include <sched.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -53,6 +56,11 @@ struct Options {
     int threads = 0;
     int level = 6;
     int precision = 1;
+    // reads are handed to the engine in slabs of at most this many bases, whatever -b says: -b is the reference's outer
+    // batch (mod_options.cpp:13), the slab is the granularity of THIS pipeline (decode | stage | GPU | tag + write overlap
+    // slab by slab).  12 Mi bases = six trunk groups, ~50 ms of device time.
+    int64_t slab_bases = int64_t(12) << 20;
+    int trunk = -1;  // -1: chosen per context from the head of the input file (the same on every rank); 0 / 1: forced
     std::vector<int> devices{0};
     std::string in, out;
     bool help = false;
@@ -68,13 +76,16 @@ void usage() {
             "  -b <int>     reads per batch (default 10000)\n"
             "  -k           keep the kinetics tags fi/ri/fp/rp in the output\n"
             "  -c <list>    contexts to call: cpg,chg,chh (default all)\n"
-            "  -t <int>     host threads for BGZF inflate/deflate and tag building (default: all)\n"
+            "  -t <int>     host threads for BGZF inflate/deflate and tag building (default: all this process is granted)\n"
             "  -d <list>    GPU ordinals, e.g. 0,1,2,3 (default 0)\n"
             "  -p <0..3>    arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA,\n"
             "               2 = fp16 weights in conv6..conv8 (|dp| <= 1e-3 mode), 3 = fp16 weights in conv2..conv8\n"
             "  -R <r/w>     this process is rank r of w: call only the r-th part of BAM (split by BGZF offset) and write\n"
             "               MOD-BAM.shard<r>; `%s merge MOD-BAM w` joins the shards in input order\n"
-            "  -z <0-9>     output compression level (default 6)\n",
+            "  -z <0-9>     output compression level (default 6)\n"
+            "  -S <int>     bases per engine slab (pipeline granularity, default 12582912; results do not depend on it)\n"
+            "  -T <0|1>     conv1..conv4 once per site (0) / once per read position (1); default: per context, from the site\n"
+            "               density of the head of BAM\n",
             kName, kName);
 }
 
@@ -92,6 +103,23 @@ bool parse_ctx(const char* arg, int& mask) {
         } else tok += s[i];
     }
     return mask != 0;
+}
+
+// host threads this process may really use: the affinity mask, capped by the cgroup CPU quota (a container that is granted
+// 16 of a node's 256 hardware threads must not start 256 workers); the reference's default is the physical core count
+// (mod_options.cpp:73,129-131)
+int default_threads() {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32];
+        long long period = 0;
+        if (fscanf(f, "%31s %lld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+            n = std::min<long long>(n, std::max<long long>(1, atoll(quota) / period));
+        fclose(f);
+    }
+    return n;
 }
 
 std::string exe_dir() {
@@ -121,6 +149,11 @@ bool parse(int argc, char** argv, Options& o) {
         else if (a == "-t") { if (!need(o.threads)) return false; }
         else if (a == "-z") { if (!need(o.level)) return false; }
         else if (a == "-p") { if (!need(o.precision)) return false; }
+        else if (a == "-T") { if (!need(o.trunk)) return false; }
+        else if (a == "-S") {
+            if (i + 1 >= argc) return false;
+            o.slab_bases = atoll(argv[++i]);
+        }
         else if (a == "-k") o.keep_kinetics = true;
         else if (a == "-c") {
             if (i + 1 >= argc || !parse_ctx(argv[++i], o.ctx_mask)) {
@@ -161,8 +194,9 @@ bool parse(int argc, char** argv, Options& o) {
     o.in = argv[i];
     o.out = argv[i + 1];
     if (o.model_dir.empty()) o.model_dir = exe_dir() + "/../weights";
-    if (o.threads <= 0) o.threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (o.threads <= 0) o.threads = default_threads();
     if (o.read_batch < 1 || o.min_read_size < 0 || o.level < 0 || o.level > 9 || o.precision < 0 || o.precision > 3) return false;
+    if (o.slab_bases < 1 || o.trunk < -1 || o.trunk > 1) return false;
     return true;
 }
 
@@ -219,6 +253,35 @@ bool open_shard(BgzfReader& in, const std::string& path, const Shard& sh, BamHea
     return true;
 }
 
+// Which contexts take the dense trunk (engine option "trunk_mask"): decided from the first reads of the FILE -- not of this
+// rank's shard -- so that every rank of a sharded run, and the single-process run, compute with the same kernels and the merged
+// output is byte-identical (the two kernel paths agree only to fp32 re-association).
+int head_trunk_mask(const Options& o, std::string& err) {
+    BgzfReader in(o.in, std::min(o.threads, 4));
+    BamHeader hdr;
+    if (!in.ok() || !read_header(in, hdr, err)) {
+        if (err.empty()) err = in.error();
+        return -1;
+    }
+    std::vector<BamRecord> recs;
+    std::vector<hm_read_t> reads;
+    int64_t bases = 0;
+    while (bases < (int64_t(4) << 20)) {
+        BamRecord r;
+        if (!read_record(in, r, err)) break;
+        bases += r.l_qseq();
+        recs.push_back(std::move(r));
+    }
+    if (!err.empty()) return -1;
+    for (const BamRecord& r : recs) {
+        hm_read_t d{};
+        d.l_qseq = r.l_qseq();
+        d.seq4 = r.seq4();
+        reads.push_back(d);
+    }
+    return hm_trunk_mask_for_reads(reads.data(), (int64_t)reads.size(), o.ctx_mask);
+}
+
 struct Job {
     hm_batch_t* batch = nullptr;
     std::vector<BamRecord> recs;
@@ -256,6 +319,11 @@ int cmd_call(int argc, char** argv) {
         hm_set_option(eng[d], "precision", o.precision);
         hm_set_option(eng[d], "slots", 3);
     }
+    {
+        int tmask = o.trunk == 0 ? 0 : o.trunk == 1 ? o.ctx_mask : head_trunk_mask(o, err);
+        if (tmask < 0) { fprintf(stderr, "[%s] %s: %s\n", kName, o.in.c_str(), err.c_str()); return EXIT_FAILURE; }
+        for (auto* e : eng) hm_set_option(e, "trunk_mask", tmask);
+    }
     size_t all_reads = 0, all_bases = 0, all_ctx[3] = {0, 0, 0};
     std::atomic<bool> failed{false};
 
@@ -271,10 +339,12 @@ int cmd_call(int argc, char** argv) {
     auto produce = [&](Batch& bt) {
         bt.recs.clear();
         bt.err.clear();
-        while ((int)bt.recs.size() < o.read_batch) {
+        int64_t bases = 0;
+        while ((int)bt.recs.size() < o.read_batch && bases < o.slab_bases) {
             if (end_off < 0 || in.block_offset() >= end_off) { bt.eof = true; break; }  // the next record is another rank's
             BamRecord r;
             if (!read_record(in, r, bt.err)) { bt.eof = true; break; }
+            bases += r.l_qseq();
             bt.recs.push_back(std::move(r));
         }
     };

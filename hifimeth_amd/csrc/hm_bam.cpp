@@ -65,6 +65,18 @@ BgzfReader::~BgzfReader() {
     if (fp_) fclose(fp_);
 }
 
+// BSIZE of a gzip member's extra field (SAMv1 4.1: subfield 'B' 'C', SLEN 2), -1 if there is none.  Subfields are
+// walked with their lengths checked against XLEN: a corrupt SLEN must not read past the field.
+static int bgzf_bsize(const uint8_t* extra, int xlen) {
+    for (int i = 0; i + 4 <= xlen;) {
+        const int slen = rd16(extra + i + 2);
+        if (i + 4 + slen > xlen) return -1;
+        if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2) return rd16(extra + i + 4);
+        i += 4 + slen;
+    }
+    return -1;
+}
+
 void BgzfReader::load(Chunk& c, int64_t from) {
     c.data.clear();
     c.segs.clear();
@@ -95,17 +107,12 @@ void BgzfReader::load(Chunk& c, int64_t from) {
             return;
         }
         const int xlen = rd16(hdr + 10);
-        uint8_t extra[256];
-        if (xlen > (int)sizeof extra || fread(extra, 1, (size_t)xlen, fp_) != (size_t)xlen) {
+        uint8_t extra[65536];  // XLEN is a 16-bit field: any valid member fits
+        if (fread(extra, 1, (size_t)xlen, fp_) != (size_t)xlen) {
             c.err = "truncated BGZF block";
             return;
         }
-        int bsize = -1;
-        for (int i = 0; i + 4 <= xlen;) {
-            const int slen = rd16(extra + i + 2);
-            if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2) bsize = rd16(extra + i + 4);
-            i += 4 + slen;
-        }
+        const int bsize = bgzf_bsize(extra, xlen);
         if (bsize < 0) {
             c.err = "BGZF block without BC field";
             return;
@@ -236,8 +243,11 @@ bool BgzfReader::seek_block(int64_t file_offset) {
     return true;
 }
 
-int64_t BgzfReader::block_offset() const {
-    if (pos_ >= cur_.data.size()) return cur_.next_off;
+int64_t BgzfReader::block_offset() {
+    // the next unread byte lies in the next chunk: look there, so that empty blocks in between (an EOF marker inside a
+    // concatenated file) are skipped and the answer is the block that really holds the byte
+    while (pos_ >= cur_.data.size())
+        if (!advance(false)) return cur_.next_off;  // end of file (an error shows up in the next read())
     int64_t off = cur_.segs.empty() ? cur_.next_off : cur_.segs.front().second;
     for (const auto& sg : cur_.segs) {
         if (sg.first > pos_) break;
@@ -264,19 +274,28 @@ bool scan_bgzf_blocks(const std::string& path, std::vector<int64_t>& offsets, in
     }
     offsets.clear();
     int64_t at = 0;
+    std::vector<uint8_t> extra(65536);
     for (;;) {
-        uint8_t hdr[18];
+        uint8_t hdr[12];
         if (fseeko(fp, (off_t)at, SEEK_SET) != 0) break;
-        const size_t got = fread(hdr, 1, 18, fp);
+        const size_t got = fread(hdr, 1, 12, fp);
         if (got == 0) break;
-        // every writer in use (htslib, this one) puts the BC subfield first: 12-byte gzip header, XLEN 6, 'B' 'C' 2 BSIZE
-        if (got != 18 || hdr[0] != 0x1f || hdr[1] != 0x8b || rd16(hdr + 10) != 6 || hdr[12] != 'B' || hdr[13] != 'C') {
-            err = "not a BGZF file (or a BGZF dialect with extra subfields)";
+        // the same member walk as BgzfReader::load: any subfield order, any XLEN
+        const int xlen = got == 12 ? rd16(hdr + 10) : 0;
+        if (got != 12 || hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4) ||
+            fread(extra.data(), 1, (size_t)xlen, fp) != (size_t)xlen) {
+            err = "not a BGZF file (bad gzip member header)";
+            fclose(fp);
+            return false;
+        }
+        const int bsize = bgzf_bsize(extra.data(), xlen);
+        if (bsize < 0 || bsize + 1 < 12 + xlen + 8) {
+            err = "BGZF block without a valid BC field";
             fclose(fp);
             return false;
         }
         offsets.push_back(at);
-        at += (int64_t)rd16(hdr + 16) + 1;
+        at += (int64_t)bsize + 1;
     }
     file_size = at;
     fclose(fp);

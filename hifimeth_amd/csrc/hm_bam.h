@@ -32,8 +32,8 @@ public:
     // ---- reading a byte range of the file (one rank of a read-sharded job inflates only its own blocks) ----
     // continue at the BGZF block that starts at compressed offset `file_offset` (buffered data is dropped)
     bool seek_block(int64_t file_offset);
-    // compressed offset of the block that holds the next unread byte (the file size once everything is consumed)
-    int64_t block_offset() const;
+    // compressed offset of the (non-empty) block that holds the next unread byte; the file size once everything is consumed
+    int64_t block_offset();
     // make up to `want` unread bytes available without consuming them; returns how many there are (fewer at EOF)
     size_t peek(const uint8_t*& p, size_t want);
     void skip(size_t n);  // consume n bytes that peek() has shown

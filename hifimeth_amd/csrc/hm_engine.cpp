@@ -153,13 +153,16 @@ struct hm_engine {
     int precision = 1;
     int max_slots = 3;  // batch slots of the asynchronous API (the legacy calls use one more, slot 0)
     // conv1..conv4: 1 = once per read position (dense trunk, hm_trunk.hip), 0 = once per site (front kernels), 2 = per
-    // context whichever is cheaper at the site density of the previous batch: the trunk costs ~0.9 ns per base and strand
+    // context whichever is cheaper at the site density of the run's first batch: the trunk costs ~0.9 ns per base and strand
     // view whatever the number of sites, the per-site kernels ~55 ns per site more than the trunk path's per-site share,
     // so the trunk wins above ~1.7 % sites per base (CHH, two views: 3.3 %) -- everything but CpG-only runs on
     // CpG-poor genomes.  Both paths give the same calls to within fp32 re-association.
     int trunk = 2;
     int trunk_impl = 1;  // 1: streaming 4-wave trunk kernel (hm_convs.h), 2: the same on 8 waves, 0: the 8-wave ConvH form
-    double density[3] = {-1, -1, -1};  // sites per base of the last finished batch (-1: none yet -> trunk)
+    // trunk = 2 is decided ONCE per engine, from the reads of the first non-empty batch that is queued (counted on the
+    // host, estimate_density): the choice must not depend on which batches happen to have finished when the next one is
+    // queued -- the two paths differ by fp32 re-association (~1e-5 in p), and the reference's output is deterministic.
+    int trunk_mask_auto = -1;  // contexts that take the dense trunk under trunk = 2 (-1: not decided yet); guarded by mu
     int64_t group_bases = int64_t(2) << 20;  // reads per trunk group: their maps take ~3.9 KB per base
     bool stamps_on = false;
     std::vector<unsigned long long> stamp_sum;
@@ -577,6 +580,60 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
     }
 }
 
+// Which contexts take the dense trunk, from a sample of reads: sites per base per context, counted on the host from the
+// 4-bit SEQ as stored (at most the first 4 Mi bases; the BAM flag is ignored: a reverse-complemented read has the same CpG
+// count and nearly the same CHG / CHH counts), same motifs as the scanners (eval_kmer_features.cpp:67-126).  The trunk costs
+// the same per base whatever the number of sites, the per-site kernels cost per site: the trunk wins above ~1.7 % sites per
+// base and strand view (CHH, two views: 3.3 %).
+struct SeqView {
+    const uint8_t* sq;
+    int len;
+};
+template <class Get>
+int trunk_mask_from_sample(size_t n, Get get, int ctx_mask) {
+    static const int8_t code[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4};  // =ACMGRSVTWYHKDBN -> A0 C1 G2 T3, else 4
+    int64_t cnt[3] = {0, 0, 0}, bases = 0;
+    for (size_t r = 0; r < n && bases < (int64_t(4) << 20); ++r) {
+        const SeqView v = get(r);
+        if (!v.sq || v.len <= 0) continue;
+        const uint8_t* sq = v.sq;
+        const int L = v.len;
+        auto at = [&](int i) { return (int)code[(sq[i >> 1] >> ((~i & 1) << 2)) & 15]; };
+        int c0 = at(0), c1 = L > 1 ? at(1) : -1;
+        for (int i = 0; i + 1 < L; ++i) {
+            const int c2 = i + 2 < L ? at(i + 2) : -1;
+            if (c0 == 1 && c1 == 2) ++cnt[CPG];
+            if (c2 >= 0) {
+                const bool h1 = c1 == 0 || c1 == 1 || c1 == 3, h2 = c2 == 0 || c2 == 1 || c2 == 3;
+                if (c0 == 1 && h1 && c2 == 2) ++cnt[CHG];
+                if (c0 == 1 && h1 && h2) ++cnt[CHH];
+                else if ((c0 == 0 || c0 == 2 || c0 == 3) && (c1 == 0 || c1 == 2 || c1 == 3) && c2 == 2) ++cnt[CHH];
+            }
+            c0 = c1;
+            c1 = c2;
+        }
+        bases += L;
+    }
+    int m = 0;
+    for (int c = 0; c < 3; ++c)
+        if ((ctx_mask >> c & 1) && bases > 0 && (double)cnt[c] >= (c == CHH ? 0.033 : 0.017) * (double)bases) m |= 1 << c;
+    return m;
+}
+
+// contexts whose conv1..conv4 run as the dense trunk for this engine
+int trunk_mask_of(hm_batch* b) {
+    hm_engine* e = b->e;
+    if (e->trunk == 0) return 0;
+    if (e->trunk == 1) return e->ctx_mask;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->trunk_mask_auto < 0) {
+        if (b->reads.n == 0) return e->ctx_mask;  // nothing to count (and nothing to run): decide with the first real batch
+        e->trunk_mask_auto = trunk_mask_from_sample(
+            b->reads.n, [&](size_t r) { return SeqView{b->slab.p + b->reads.p[r].off_seq, b->reads.p[r].len}; }, e->ctx_mask);
+    }
+    return e->trunk_mask_auto;
+}
+
 // scanner + CNN + pack on the compute stream, then the totals' D2H on the slot stream; returns without waiting
 void enqueue_run(hm_batch* b) {
     hm_engine* e = b->e;
@@ -602,12 +659,7 @@ void enqueue_run(hm_batch* b) {
                     b->d_csites.as<Site>(), b->d_opos.as<int32_t>());
         sp.end();
     }
-    int trunk_mask = 0;  // contexts whose conv1..conv4 run as the dense trunk
-    if (e->trunk)
-        for (int c = 0; c < 3; ++c) {
-            const double thr = c == CHH ? 0.033 : 0.017;
-            if ((e->ctx_mask >> c & 1) && (e->trunk == 1 || e->density[c] < 0 || e->density[c] >= thr)) trunk_mask |= 1 << c;
-        }
+    const int trunk_mask = trunk_mask_of(b);  // contexts whose conv1..conv4 run as the dense trunk
     if (trunk_mask) run_trunk_path(b, spans, trunk_mask);
     if ((e->ctx_mask & ~trunk_mask) != 0) {
     // The CNN launches cover [0, bound) of every context's list in windows of `sb` sites; how many sites a window
@@ -653,10 +705,6 @@ int wait_totals(hm_batch* b) {
         HIP_TRY(hipEventSynchronize(b->ev_out));
         memcpy(b->totals, b->h_totals, sizeof b->totals);
         b->have_totals = true;
-        if (b->total_bases > 0) {
-            std::lock_guard<std::mutex> lk(e->mu);
-            for (int c = 0; c < 3; ++c) e->density[c] = (double)b->totals[c] / (double)b->total_bases;
-        }
         collect_timing(e, b->spans, b->totals);
     }
     if (*b->h_err) {
@@ -776,9 +824,15 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
         if (value < TAIL_SITES) return fail(e, HM_EINVAL, "sub_batch_sites too small");
         e->sub_batch = value / TAIL_SITES * TAIL_SITES;
     } else if (k == "trunk") {
-        if (value < 0 || value > 2) return fail(e, HM_EINVAL, "trunk must be 0 (per site), 1 (dense trunk) or 2 (by site density)");
+        if (value < 0 || value > 2) return fail(e, HM_EINVAL, "trunk must be 0 (per site), 1 (dense trunk) or 2 (by the site density of the first batch)");
+        std::lock_guard<std::mutex> lk(e->mu);
         e->trunk = (int)value;
-        for (double& d : e->density) d = -1;
+        e->trunk_mask_auto = -1;
+    } else if (k == "trunk_mask") {  // the choice of "trunk" = 2 made by the caller (hm_trunk_mask_for_reads): bit c = context c takes the trunk
+        if (value < 0 || value > 7) return fail(e, HM_EINVAL, "trunk_mask must be 0..7");
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->trunk = 2;
+        e->trunk_mask_auto = (int)value & e->ctx_mask;
     } else if (k == "trunk_impl") {
         if (value < 0 || value > 2) return HM_EINVAL;
         e->trunk_impl = (int)value;
@@ -956,16 +1010,25 @@ int64_t hm_batch_submit_reads(hm_batch_t* b, const hm_read_t* reads, int64_t n, 
             need_total += align16((L + 1) / 2) + 4 * align16(L * 2);
         }
         if (b->slab.n + need_total > b->slab.cap) b->slab.reserve(std::max<size_t>(b->slab.n + need_total, size_t(64) << 20));
+        // every read is checked before the first one is placed: an error leaves the batch exactly as it was
+        {
+            int64_t tb = b->total_bases;
+            for (int64_t i = 0; i < n; ++i) {
+                const hm_read_t& r = reads[i];
+                if (r.l_qseq < 0) return fail(e, HM_EINVAL, "hm_batch_submit_reads: negative read length");
+                if (r.l_qseq < e->min_read_size || !r.kin[0] || !r.kin[1] || !r.kin[2] || !r.kin[3]) continue;
+                if (!r.seq4) return fail(e, HM_EINVAL, "hm_batch_submit_reads: seq4 is NULL");
+                for (int k = 0; k < 4; ++k)
+                    if (r.width[k] != 1 && r.width[k] != 2) return fail(e, HM_EINVAL, "kinetics element width must be 1 (B:C) or 2 (B:S)");
+                if (tb + (int64_t)r.l_qseq + 4 >= (int64_t(1) << 31))
+                    return fail(e, HM_ENOMEM, "hm_batch_submit_reads: batch would exceed 2^31 bases; nothing was staged -- submit fewer reads per batch");
+                tb += ((int64_t)r.l_qseq + 3) & ~int64_t(3);
+            }
+        }
         for (int64_t i = 0; i < n; ++i) {
             const hm_read_t& r = reads[i];
             if (accepted) accepted[i] = 0;
-            if (r.l_qseq < 0) return fail(e, HM_EINVAL, "hm_batch_submit_reads: negative read length");
             if (r.l_qseq < e->min_read_size || !r.kin[0] || !r.kin[1] || !r.kin[2] || !r.kin[3]) continue;
-            if (!r.seq4) return fail(e, HM_EINVAL, "hm_batch_submit_reads: seq4 is NULL");
-            if (b->total_bases + (int64_t)r.l_qseq + 4 >= (int64_t(1) << 31))
-                return fail(e, HM_ENOMEM, "hm_batch_submit_reads: batch would exceed 2^31 bases; queue it first");
-            for (int k = 0; k < 4; ++k)
-                if (r.width[k] != 1 && r.width[k] != 2) return fail(e, HM_EINVAL, "kinetics element width must be 1 (B:C) or 2 (B:S)");
             const size_t L = (size_t)r.l_qseq;
             ReadDesc rd{};
             auto place = [&](const void* src, size_t bytes) {
@@ -1019,6 +1082,11 @@ int64_t hm_batch_submit_reads(hm_batch_t* b, const hm_read_t* reads, int64_t n, 
         for (auto& th : pool) th.join();
     }
     return taken;
+}
+
+int hm_trunk_mask_for_reads(const hm_read_t* reads, int64_t n, int ctx_mask) {
+    if ((!reads && n > 0) || n < 0) return HM_EINVAL;
+    return trunk_mask_from_sample((size_t)n, [&](size_t r) { return SeqView{reads[r].seq4, reads[r].l_qseq}; }, ctx_mask & 7);
 }
 
 int64_t hm_batch_staged_bases(const hm_batch_t* b) { return b ? b->total_bases : HM_EINVAL; }

@@ -95,6 +95,59 @@ def synth_reads(n_reads: int, seed: int = 20250220, gc: float = 0.36, median_len
     return out
 
 
+def write_unaligned_bam(path: str, reads, level: int = 1, threads: int = 8,
+                        header_text: str = "@HD\tVN:1.6\tSO:unknown\tpb:5.0.0\n") -> int:
+    """PacBio-style unaligned BAM of `reads` (fi / fp / ri / rp as B:C or B:S, plus np / rq / RG / zm), BGZF blocks deflated
+    on `threads` threads (zlib releases the GIL) -- the same records tests/bamutil.reads_to_bam writes, fast enough for the
+    GB-sized inputs of the end-to-end benchmark.  Returns the number of payload bytes."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    def block(data: bytes) -> bytes:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(data) + co.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 18 + len(comp) + 8 - 1) + comp
+                + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+
+    def aux_b(tag: bytes, a) -> bytes:
+        a = np.ascontiguousarray(a)
+        return tag + (b"BC" if a.dtype.itemsize == 1 else b"BS") + struct.pack("<I", len(a)) + a.astype(a.dtype.newbyteorder("<")).tobytes()
+
+    BLK = 0xff00
+    total = 0
+    with open(path, "wb") as f, ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        buf = bytearray(b"BAM\1" + struct.pack("<I", len(header_text)) + header_text.encode() + struct.pack("<I", 0))
+
+        def drain(final: bool):
+            nonlocal buf, total
+            n = len(buf) if final else len(buf) // BLK * BLK
+            if n == 0:
+                return
+            mv = bytes(buf[:n])
+            for comp in ex.map(block, (mv[i:i + BLK] for i in range(0, n, BLK))):
+                f.write(comp)
+            total += n
+            del buf[:n]
+
+        for i, r in enumerate(reads):
+            aux = b"npi" + struct.pack("<i", 10 + i) + b"rqf" + struct.pack("<f", 0.999) + b"RGZrg0\0"
+            for tag in ("fi", "fp", "ri", "rp"):
+                a = getattr(r, tag)
+                if a is not None:
+                    aux += aux_b(tag.encode(), a)
+            aux += b"zmi" + struct.pack("<i", i)
+            qn = r.name.encode() + b"\0"
+            core = struct.pack("<iiBBHHHiiii", -1, -1, len(qn), 255, 4680, 0, r.flag, r.l_qseq, -1, -1, 0)
+            body_len = len(core) + len(qn) + len(r.seq4) + r.l_qseq + len(aux)
+            buf += struct.pack("<I", body_len) + core + qn + bytes(r.seq4) + b"\xff" * r.l_qseq + aux
+            if len(buf) >= (64 << 20):
+                drain(False)
+        drain(True)
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return total
+
+
 _QTAB = {}
 
 

@@ -91,8 +91,10 @@ const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a fa
  * 1 = split-half fp16x3 MFMA with fp32 accumulate (default); 2 = 1 with plain fp16 WEIGHTS in conv6..conv8, the part of the
  * network where they hold BASELINE.json configs[4]'s bar |dp| <= 1e-3 (tools/w16_error_table.py); 3 = fp16 weights in
  * conv2..conv8, the literal configs[4], which misses that bar (max |dp| ~ 2.5e-3): kept for the record; activations stay
- * split and accumulation fp32 in every mode), "trunk" (2 = per context by site density, default; 1 = conv1..conv4 once per
- * read position; 0 = once per site; every precision has both forms), "trunk_impl" (1 = streaming 4-wave trunk kernel,
+ * split and accumulation fp32 in every mode), "trunk" (2 = per context by the site density of the FIRST batch the engine is given -- counted
+ * on the host when that batch is queued and then fixed for the engine's lifetime, so the calls never depend on host timing --
+ * default; 1 = conv1..conv4 once per read position; 0 = once per site; every precision has both forms), "trunk_mask" (0..7: that
+ * choice made by the caller, see hm_trunk_mask_for_reads), "trunk_impl" (1 = streaming 4-wave trunk kernel,
  * default; 2 = the same on 8 waves; 0 = the 8-wave ConvH form; byte-identical results), "group_bases" (reads per trunk group, default 2 Mi bases),
  * "stamps" (diagnostic) */
 int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
@@ -130,7 +132,9 @@ int hm_batch_submit_read(hm_batch_t* b, int32_t read_id, int32_t l_qseq, int32_t
                          const void* rp, int rp_width);
 /* Bulk form: n reads in one call, copied into the slab by `threads` host threads (the per-read layout is fixed by a
  * serial pass first, so the result is identical to n hm_batch_submit_read calls in order).  A read that would be passed
- * through uncalled is skipped exactly as there; accepted[i] (may be NULL) tells which.  Returns the number accepted. */
+ * through uncalled is skipped exactly as there; accepted[i] (may be NULL) tells which.  Returns the number accepted.
+ * All n reads are validated before the first is placed: on an error (HM_EINVAL, HM_ENOMEM = the batch would pass 2^31
+ * bases) the batch is exactly as it was before the call. */
 typedef struct {
     int32_t read_id, l_qseq, flag;
     uint8_t width[4];     /* element width of fi, fp, ri, rp: 1 (B:C) or 2 (B:S) */
@@ -138,6 +142,12 @@ typedef struct {
     const void* kin[4];   /* fi, fp, ri, rp; NULL = tag missing */
 } hm_read_t;
 int64_t hm_batch_submit_reads(hm_batch_t* b, const hm_read_t* reads, int64_t n, int threads, uint8_t* accepted);
+/* The per-context choice the engine makes under "trunk" = 2, as a function of a sample of reads (host only, no device work,
+ * only seq4 / l_qseq are read): bit c set = context c takes the dense trunk.  A front end that shards one input over several
+ * engines or ranks passes the SAME sample (the head of the file) everywhere and sets the result with the "trunk_mask" option,
+ * so that every shard computes with the same kernels and the merged output equals the single-process output byte for byte
+ * (the reference's output is deterministic: mod_main.cpp:330-362). */
+int hm_trunk_mask_for_reads(const hm_read_t* reads, int64_t n, int ctx_mask);
 int64_t hm_batch_staged_bases(const hm_batch_t* b);
 /* Queues the batch: async H2D on the slot's stream, scanner + CNN + result packing on the engine's compute stream (site
  * counts are consumed on the device), async D2H of the totals.  Returns at once; batches compute in queueing order. */

@@ -112,3 +112,18 @@ def test_cxx_hmw_roundtrip_and_rejects_garbage(tmp_path):
     junk = tmp_path / "junk.onnx"
     junk.write_bytes(os.urandom(4096))
     assert L.hm_convert_model(str(junk).encode(), out.encode()) < 0
+
+
+def test_trunk_mask_for_reads_is_a_host_function_of_the_sample():
+    """hm_trunk_mask_for_reads (no device needed): which contexts take the dense trunk follows from the site density of the
+    sample alone -- CpG-poor reads send CpG / CHG to the per-site kernels, CHH stays dense; ctx_mask masks the answer; the
+    same sample always gives the same answer (the CLI passes the head of the file to every rank)."""
+    from hifimeth_amd.caller import ReadBlock, trunk_mask_for_reads
+    from hifimeth_amd.synth import expected_sites_per_base, synth_reads
+    rich = ReadBlock(synth_reads(8, seed=3, gc=0.36, median_len=3000, frac_missing=0, frac_short=0))
+    poor = ReadBlock(synth_reads(8, seed=4, gc=0.11, median_len=3000, frac_missing=0, frac_short=0))
+    assert expected_sites_per_base(0.36) > 0.25
+    assert trunk_mask_for_reads(rich) == 7 and trunk_mask_for_reads(rich, 1) == 1 and trunk_mask_for_reads(rich, 6) == 6
+    assert trunk_mask_for_reads(poor) == 4 and trunk_mask_for_reads(poor, 3) == 0   # (0.055)^2 = 0.3 % CpG; CHH ~ 9 %
+    assert trunk_mask_for_reads(ReadBlock([])) == 0
+    assert trunk_mask_for_reads(poor) == trunk_mask_for_reads(ReadBlock(poor.reads))

@@ -201,6 +201,33 @@ def test_cli_call_sharded_over_ranks_matches_single_rank(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_default_flags_cut_batches_into_slabs_without_changing_the_output(tmp_path):
+    """`-b` keeps the reference's meaning (reads per outer batch, default 10000: mod_options.cpp:10-17) but no longer sets the
+    granularity of the GPU pipeline: a batch is cut into engine slabs of <= 12 Mi bases (-S).  2 000 reads (~30 Mbases) with
+    the default flags, with -b 250 and with tiny slabs must give byte-identical BAM payloads -- the calls do not depend
+    on the batch cut (mod_main.cpp:330-362) -- and the default run must have used more than one slab."""
+    import gzip
+    reads = synth_reads(2000, seed=20250221)
+    src = str(tmp_path / "in.bam")
+    bamutil.reads_to_bam(src, reads, level=1)
+    outs = []
+    for tag, extra in (("default", []), ("b250", ["-b", "250"]), ("tiny", ["-S", "300000", "-b", "9999"])):
+        dst = str(tmp_path / f"{tag}.bam")
+        r = subprocess.run([CLI, "call", "-t", "8"] + extra + [src, dst], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        slabs = r.stderr.count("reads done")
+        outs.append((tag, slabs, gzip.open(dst, "rb").read()))
+    assert outs[0][1] >= 2 and outs[1][1] == 8 and outs[2][1] > 50, [(t, n) for t, n, _ in outs]
+    # the @PG line records the command line (mod_main.cpp:101-117): compare everything behind the header text
+    def body(raw):
+        l_text = int.from_bytes(raw[4:8], "little")
+        return raw[8 + l_text:]
+    assert body(outs[0][2]) == body(outs[1][2]) == body(outs[2][2])
+    _, recs = bamutil.read_bam(str(tmp_path / "default.bam"))
+    assert len(recs) == len(reads) and sum(1 for x in recs if b"MM" in x["aux"]) > 1900
+
+
+@pytest.mark.gpu
 def test_call_dist_two_ranks_launched_like_a_multi_gpu_job(tmp_path):
     """python -m torch.distributed.run --nproc-per-node 2 -m hifimeth_amd.call_dist: one process per rank, each calls its
     BGZF-offset shard through the native front end (both on this box's one GPU; gloo for the barrier), rank 0 merges.
@@ -214,7 +241,9 @@ def test_call_dist_two_ranks_launched_like_a_multi_gpu_job(tmp_path):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, PYTHONPATH=ROOT, HM_DIST_BACKEND="gloo")
+    # launched exactly as documented: no HM_DIST_BACKEND override (the ranks' barrier is a CPU collective: gloo by default)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("HM_DIST_BACKEND", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), "-m", "hifimeth_amd.call_dist", "-t", "4", src, two],
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)

@@ -154,3 +154,39 @@ def test_two_rank_call_driver_over_a_bam_file(tmp_path):
         p.join(120)
         assert p.exitcode == 0
     assert _payload(out) == _payload(one)
+
+
+def _missing_cli_worker(rank, world, port, src, out, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.pop("HM_DIST_BACKEND", None)
+    import sys
+    sys.path.insert(0, ROOT)
+    from hifimeth_amd import call_dist
+    if rank == 1:
+        call_dist.CLI = "/nonexistent/hifimeth-hip"      # this rank cannot start its child
+    q.put((rank, call_dist.run(["--copy", src, out])))   # default backend: gloo, no GPU touched
+
+
+def test_call_driver_rank_that_cannot_start_its_child_fails_the_job_without_a_hang(tmp_path):
+    """One rank fails to launch the native front end (OSError): it must still reach the collective, so that the others do not
+    block until the process-group timeout; every rank returns non-zero and nothing is merged.  Runs with the DEFAULT backend
+    (no HM_DIST_BACKEND): the ranks' barrier is a CPU collective."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bamutil
+    from hifimeth_amd.synth import synth_reads
+    src, out = str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
+    bamutil.reads_to_bam(src, synth_reads(6, seed=3, median_len=2000, sigma=0.2), level=1)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_missing_cli_worker, args=(r, 2, port, src, out, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    rcs = dict(q.get(timeout=5) for _ in range(2))
+    assert rcs[0] != 0 and rcs[1] != 0 and not os.path.exists(out)

@@ -43,7 +43,14 @@ def test_bench_line_single_gpu_with_cpu_baseline():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "sites/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert d["parity"]["max_abs_dp_vs_oracle"] <= d["parity"]["tolerance"] == 1e-4
-    assert d["parity"]["sites_checked"] > 10000
+    assert d["parity"]["sites_checked"] > 10000 and "STREAMED" in d["parity"]["sample"]
+    rf = d["roofline"]
+    assert 0 < rf["utilisation"] < 1 and abs(rf["utilisation"] - rf["frac_executed"]) < 1e-12 and rf["algorithmic_bytes"] > 0
+    assert rf["traffic"] is None or (rf["traffic"] > rf["algorithmic_bytes"] and rf["quoted"].startswith("profiles/"))
+    e2e = d["end_to_end"]
+    assert "error" not in e2e, e2e
+    assert e2e["value"] > 0 and e2e["unit"] == "sites/s" and e2e["reads"] == 36 and e2e["host_threads"] >= 1
+    assert e2e["sites"] > 100000 and "defaults" in e2e["flags"]
 
 
 def test_bench_rccl_world_of_one():

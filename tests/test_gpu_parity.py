@@ -457,22 +457,72 @@ def test_batch_pipeline_matches_synchronous_calls(mc):
         assert ns[3] == len(w) and sum(ns[:3]) == ns[3] and [int((w["ctx"] == c).sum()) for c in range(3)] == ns[:3]
 
 
-def test_path_follows_site_density(oracle, oracle_models):
+def test_path_follows_site_density_of_the_first_batch(oracle, oracle_models):
     """Option trunk=2 (default): per context, conv1..conv4 run as the dense trunk or per site, whichever is cheaper at the
-    site density of the previous batch.  A CpG-only run on a CpG-poor genome (0.3 % sites per base) switches to the
-    per-site kernels after its first batch; both batches hold the 1e-4 bar and agree with each other to ~1e-5."""
+    site density of the engine's FIRST batch -- counted on the host when that batch is queued and then fixed, so the same
+    input always takes the same kernels whatever the host timing (the reference's output is deterministic).  A CpG-only run
+    on a CpG-poor genome (0.3 % sites per base) takes the per-site kernels from its first batch on, and keeps them when a
+    CpG-rich batch follows; "trunk_mask" lets a front end make the choice itself; both paths hold the 1e-4 bar and agree to
+    ~1e-5."""
     from hifimeth_amd import MethylationCaller
+    from hifimeth_amd.caller import ReadBlock, trunk_mask_for_reads
     reads = synth_reads(6, seed=123, gc=0.11, median_len=5000, sigma=0.2, frac_short=0, frac_missing=0, frac_wide=0)
+    rich = synth_reads(3, seed=124, gc=0.5, median_len=3000, sigma=0.2, frac_short=0, frac_missing=0, frac_wide=0)
+    assert trunk_mask_for_reads(ReadBlock(reads), 1) == 0 and trunk_mask_for_reads(ReadBlock(rich), 1) == 1
     with MethylationCaller(contexts="cpg", timing=True) as m:
-        a = m.call(reads).copy()
-        t1 = m.timing(reset=True)
         b = m.call(reads).copy()
-        t2 = m.timing()
-    assert sum(t1["trunk_launches"]) > 0 and sum(t1["front_launches"]) == 0      # first batch: density unknown -> trunk
-    assert sum(t2["trunk_launches"]) == 0 and sum(t2["front_launches"]) > 0      # then: 0.3 % < 1.7 % -> per site
+        t1 = m.timing(reset=True)
+        b2 = m.call(reads).copy()
+        m.call(rich)
+        t2 = m.timing(reset=True)
+        assert sum(t1["trunk_launches"]) == 0 and sum(t1["front_launches"]) > 0      # decided before the first launch
+        assert sum(t2["trunk_launches"]) == 0 and sum(t2["front_launches"]) > 0      # and kept
+        assert b.tobytes() == b2.tobytes()
+        m.set_option("trunk_mask", 1)
+        a = m.call(reads).copy()
+        t3 = m.timing()
+        assert sum(t3["trunk_launches"]) > 0 and sum(t3["front_launches"]) == 0
     assert len(a) == len(b) > 20 and np.array_equal(a["qoff"], b["qoff"]) and np.abs(a["p"] - b["p"]).max() < 2e-5
-    n, nml, worst = _check_calls(b, reads, oracle, oracle_models, 1)
-    assert n == len(b) and worst <= DP_TOL
+    for calls in (a, b):
+        n, nml, worst = _check_calls(calls, reads, oracle, oracle_models, 1)
+        assert n == len(calls) and worst <= DP_TOL
+
+
+def test_trunk_groups_do_not_change_the_calls(oracle, oracle_models):
+    """The dense trunk cuts a batch into read groups that reuse one set of map buffers (engine option group_bases, default
+    2 Mi bases; bench.py's steps run ~38 groups per context).  With group_bases = 32 Ki the same reads fall into many groups
+    -- a read that ends a group, a read that starts one, a 70 kb read that is a group of its own, a crowd of minimum-length
+    reads -- and the calls must be byte-identical to the one-group run and within 1e-4 of the oracle: results may not
+    depend on the batch cut (mod_main.cpp:330-362), in the split-half and in the strict-fp32 arithmetic."""
+    from hifimeth_amd import MethylationCaller
+    rng = np.random.default_rng(41)
+
+    def rnd(L, wide=False):
+        return read_from_ascii("".join("ACGT"[i] for i in rng.choice(4, L, p=[0.32, 0.18, 0.18, 0.32])).encode(), *_kin(L, rng, wide))
+
+    # group boundaries at >= 32768 bases: [A 20000, B 13000] | [C 70001] | [D 32768] | [E 1000 x 33] | [F 9000, G 24000] | ...
+    reads = [rnd(20000), rnd(13000), rnd(70001), rnd(32768), *[rnd(1000) for _ in range(33)], rnd(9000), rnd(24000, wide=True)]
+    reads += synth_reads(6, seed=43, median_len=12000, sigma=0.4, frac_wide=0.3, frac_short=0, frac_missing=0)
+    assert len(reads) >= 12
+    for precision in (1, 0):
+        with MethylationCaller(device=0, timing=True) as m:
+            m.set_option("precision", precision)
+            m.set_option("trunk", 1)
+            one = m.call(reads).copy()
+            t_one = m.timing(reset=True)
+            m.set_option("group_bases", 32768)
+            many = m.call(reads).copy()
+            t_many = m.timing(reset=True)
+            # the streamed form of the same thing: slabs of the asynchronous pipeline, several groups each
+            got = []
+            m.stream([reads[:4], reads[4:]], on_batch=lambda k, b, c: got.append(c.copy()))
+        assert sum(t_one["trunk_launches"]) == 3 and sum(t_many["trunk_launches"]) >= 3 * 8, (t_one["trunk_launches"], t_many["trunk_launches"])
+        assert len(one) > 60000 and one.tobytes() == many.tobytes()
+        second = got[1].copy()
+        second["read_id"] += 4
+        assert np.concatenate([got[0], second]).tobytes() == one.tobytes()
+        n, nml, worst = _check_calls(many, reads, oracle, oracle_models, 7)
+        print(f"precision {precision}: {sum(t_many['trunk_launches'])} trunk launches, {n} sites, max|dp|={worst:.2e}, ML off by one: {nml}")
 
 
 def test_bulk_submit_matches_read_by_read(mc):
