@@ -159,6 +159,7 @@ struct hm_engine {
     // CpG-poor genomes.  Both paths give the same calls to within fp32 re-association.
     int trunk = 2;
     int trunk_impl = 1;  // 1: streaming 4-wave trunk kernel (hm_convs.h), 2: the same on 8 waves, 0: the 8-wave ConvH form
+    int tail_impl = 1;   // dense-trunk path, precision 1: 1 = tail with resident weights (hm_tail_r.hip), 0 = tail_kernel_h (streams them per pass)
     // trunk = 2 is decided ONCE per engine, from the reads of the first non-empty batch that is queued (counted on the
     // host, estimate_density): the choice must not depend on which batches happen to have finished when the next one is
     // queued -- the two paths differ by fp32 re-association (~1e-5 in p), and the reference's output is deterministic.
@@ -572,8 +573,12 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
             }
             {
                 Span sp(e, spans, K_TAILG, c);
-                launch_tail_gather(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
-                                   b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu, e->precision - 1);
+                if (e->tail_impl == 1 && e->precision == 1)
+                    launch_tail_gather_r(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
+                                         b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu);
+                else
+                    launch_tail_gather(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
+                                       b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu, e->precision - 1);
                 sp.end();
             }
         }
@@ -836,6 +841,9 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
     } else if (k == "trunk_impl") {
         if (value < 0 || value > 2) return HM_EINVAL;
         e->trunk_impl = (int)value;
+    } else if (k == "tail_impl") {
+        if (value < 0 || value > 1) return fail(e, HM_EINVAL, "tail_impl must be 0 or 1");
+        e->tail_impl = (int)value;
     } else if (k == "group_bases") {
         if (value < 1) return fail(e, HM_EINVAL, "group_bases must be positive");
         e->group_bases = value;

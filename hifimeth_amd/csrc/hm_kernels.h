@@ -71,6 +71,9 @@ void launch_edge(hipStream_t st, int k1, const SiteRange& sr, const RInfo* rinfo
                  bool w16);
 void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
                         const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, int w16_level);
+// the same tail with conv5..conv7's weights resident in registers (hm_tail_r.hip): bit-identical results
+void launch_tail_gather_r(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
+                          const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid);
 void launch_trunk2(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,
                    const TrunkMaps& maps, int grid, bool w16, bool waves8 = false);

@@ -1,0 +1,41 @@
+"""Diagnostic: where a pass of tail_kernel_r goes (stamped build: make -C hifimeth_amd/csrc stamp;
+HM_LIB_PATH=hifimeth_amd/libhifimeth_hip_stamp.so python tools/tailr_stamps.py).  s_memtime ticks per 8-site pass of
+workgroup 0, one column per wave; shares of a pass, not clock cycles (the tick rate depends on the load)."""
+import ctypes as C
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from hifimeth_amd import MethylationCaller, _lib  # noqa: E402
+from hifimeth_amd.synth import synth_reads  # noqa: E402
+
+reads = synth_reads(400, seed=5)
+mc = MethylationCaller(device=0, timing=True)
+mc.set_option("trunk", 1)
+mc.set_option("tail_impl", 1)
+mc.submit_all(reads)
+mc.upload()
+mc.run()
+mc.sync()
+fn = C.CDLL(_lib.LIB_PATH).hm_debug_tailr_stamps
+fn.argtypes = [C.c_void_p, C.c_int]
+fn(None, 1)
+mc.timing(reset=True)
+for _ in range(3):
+    mc.run()
+mc.sync()
+buf = np.zeros((4, 16), np.uint64)
+assert fn(buf.ctypes.data, 0) == 0
+n = float(buf[0, 11])
+print("passes of workgroup 0:", int(n), " fc batches:", int(buf[0, 10]), " sites", mc.num_sites(3))
+names = ["conv5 part 1 (+late-row DMA)", "drain + barrier", "table + conv5 part 2", "barrier", "conv6 (+early-row DMA)", "barrier",
+         "conv7", "drain + barrier", "conv8", "fc1 + fc2 per pass"]
+tot = np.zeros(4)
+for i, nm in enumerate(names):
+    v = buf[:, i].astype(float) / n
+    tot += v
+    print(f"{nm:30s} " + " ".join(f"{x:7.0f}" for x in v))
+print(f"{'sum':30s} " + " ".join(f"{x:7.0f}" for x in tot))
+tm = mc.timing()
+print("tail_ms per run", [round(x / 3, 2) for x in tm["tail_ms"]])
