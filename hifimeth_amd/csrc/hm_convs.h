@@ -109,7 +109,10 @@ struct SConvR {
         const uint8_t* rows = nullptr;
         half_t* g = nullptr;
     };
-    template <class Epi, class Copy = NoCopy>
+    // J0: the first of this layer's NTW n-tiles among the wave's resident ones (W.w[.][J0 ..]); nt0 is resident tile 0's
+    // n-tile.  A wave that holds two n-tiles may run one of them alone over some positions (NTW = 1, J0 = 0 | 1): conv4's
+    // 6 x 7 tile pairs are dealt to four waves that way (hm_trunk.hip).
+    template <int J0 = 0, class Epi, class Copy = NoCopy>
     static __device__ __forceinline__ void run(const half_t* __restrict__ in_hi, const half_t* __restrict__ in_lo, WRegs& W,
                                                Epi epi, const half_t* __restrict__ wnext, const float* __restrict__ bnext,
                                                int nt0, int nt0n, Copy cp = Copy{}) {
@@ -153,7 +156,7 @@ struct SConvR {
 #pragma unroll
                 for (int i = 0; i < G; ++i)
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j) acc[g & 1][i][j] = f32x4{W.bz[j].x, W.bz[j].y, W.bz[j].z, W.bz[j].w};
+                    for (int j = 0; j < NTW; ++j) acc[g & 1][i][j] = f32x4{W.bz[J0 + j].x, W.bz[J0 + j].y, W.bz[J0 + j].z, W.bz[J0 + j].w};
             }
             // the next layer's bias goes first of its loads (vector memory returns in order: the first MFMA of the next layer
             // needs the bias, and would otherwise wait for every weight fragment issued before it)
@@ -167,7 +170,7 @@ struct SConvR {
                 for (int i = 0; i < G; ++i)
 #pragma unroll
                     for (int j = 0; j < NTW; ++j)
-                        acc[g & 1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.w[kb][j][pr == 2 ? 1 : 0], x[c % XS][i][pr == 1 ? 1 : 0],
+                        acc[g & 1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.w[kb][J0 + j][pr == 2 ? 1 : 0], x[c % XS][i][pr == 1 ? 1 : 0],
                                                                                  acc[g & 1][i][j], 0, 0, 0);
             }
             constexpr int NA = g > 0 ? gs[g > 0 ? g - 1 : 0] * NTW : 0;  // accumulators of the previous group
@@ -176,7 +179,7 @@ struct SConvR {
 #pragma unroll
                 for (int a = A0; a < A1; ++a) {
                     const int m = (tile0(g - 1) + a / NTW) * 16 + li;
-                    if ((tile0(g - 1) + a / NTW + 1) * 16 <= RM::M || m < RM::M) epi(m, (nt0 + a % NTW) * 16 + 4 * lk, acc[(g - 1) & 1][a / NTW][a % NTW]);
+                    if ((tile0(g - 1) + a / NTW + 1) * 16 <= RM::M || m < RM::M) epi(m, (nt0 + J0 + a % NTW) * 16 + 4 * lk, acc[(g - 1) & 1][a / NTW][a % NTW]);
                 }
             }
             if constexpr (c >= 2 && c < CS + 2)
@@ -193,7 +196,7 @@ struct SConvR {
                 constexpr int NPN = CNN::WLO ? 2 : 1, EN = CNN::KB * CNN::NTW * NPN;
                 auto is_free = [](int e) constexpr {
                     const int kb2 = e / (CNN::NTW * NPN), j2 = e / NPN % CNN::NTW, p2 = e % NPN;
-                    return kb2 >= KB || j2 >= NTW || p2 >= (C::WLO ? 2 : 1);
+                    return kb2 >= KB || j2 < J0 || j2 >= J0 + NTW || p2 >= (C::WLO ? 2 : 1);
                 };
                 constexpr int NFREE = [&]() constexpr { int n = 0; for (int e = 0; e < EN; ++e) n += is_free(e); return n; }();
                 constexpr int NEARLY = NB - KB;  // blocks before the last group
@@ -234,7 +237,7 @@ struct SConvR {
 #pragma unroll
             for (int a = 0; a < gs[g] * NTW; ++a) {
                 const int m = (tile0(g) + a / NTW) * 16 + li;
-                if ((tile0(g) + a / NTW + 1) * 16 <= RM::M || m < RM::M) epi(m, (nt0 + a % NTW) * 16 + 4 * lk, acc[g & 1][a / NTW][a % NTW]);
+                if ((tile0(g) + a / NTW + 1) * 16 <= RM::M || m < RM::M) epi(m, (nt0 + J0 + a % NTW) * 16 + 4 * lk, acc[g & 1][a / NTW][a % NTW]);
             }
         }
     }

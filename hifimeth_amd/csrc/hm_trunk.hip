@@ -425,13 +425,19 @@ void trunk2_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     using C1 = SCfg<8, (2 * K1 + 3) / 4 * 4, TR_WRS, 1, true, false, K1, 2, NTW>;
     using C2 = SCfg<128, 3, TR_RS, 2, !W16, true, 0, 1, NTW>;
     using C3 = SCfg<128, 3, TR_RS, 4, !W16, true, 0, 1, NTW>;
-    // conv4 (96 channels) on three waves, two channel tiles each, all positions; the fourth copies the E3 rows out.  (Three
-    // tiles x half the positions on four waves needs 288 weight registers per wave and spills: scratch traffic shares the
-    // vector-memory counter and every wait behind it becomes conservative.)
+    // conv4: 96 channels = 6 n-tiles x 7 position tiles = 42 tile pairs.  Four waves: a wave holds TWO n-tiles (a, b) -- 192
+    // weight registers, like every other layer -- and runs the pair on one range of position tiles and a alone on the other,
+    // b being shared by two waves that take complementary ranges: 11 + 10 + 11 + 10 tile pairs.  (Until round 3 three waves
+    // took 14 pairs each and the fourth copied the E3 rows out, waiting a fifth of the tile at the barrier; three n-tiles
+    // x half the positions on four waves needs 288 weight registers and spills.)  The E3 copy slots ride in all four waves.
+    // Eight waves (trunk_impl = 2): six of them one n-tile each, as before.
+    constexpr bool SPLIT4 = NW == 4;
     using C4 = SCfg<128, 3, TR_RS, 8, !W16, true, 0, 1, NTW>;
+    using C4s = SCfg<128, 3, TR_RS, 8, !W16, true, 0, 1, 1>;   // one of the wave's two resident n-tiles alone
     using L4 = SConv<C4, C1, 0, 4, 3>;
-    constexpr int NW4 = 6 / NTW;  // waves with channels in conv4
-    const int nt04 = wave < NW4 ? NTW * wave : 6 - NTW;
+    constexpr int NW4 = SPLIT4 ? NW : 6 / NTW;  // waves with channels in conv4
+    // resident n-tiles nt04, nt04 + 1: waves 0 / 2 hold (a, b) = (0, 1) / (3, 4), waves 1 / 3 hold (b, a) = (1, 2) / (4, 5)
+    const int nt04 = SPLIT4 ? (wave == 0 ? 0 : wave == 1 ? 1 : wave == 2 ? 3 : 4) : (wave < NW4 ? NTW * wave : 6 - NTW);
     using L1 = SConv<C1, C2, 0, 3, 3, 3>;
     using L2 = SConv<C2, C3, 0, 2, 3, 4>;  // the longest group last: it is the window in which conv3's weights can be fetched
     using L3 = SConv<C3, C4, 0, 4, 4>;
@@ -487,7 +493,17 @@ void trunk2_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         __syncthreads();
         TS(6);
         const EpiE4S e4{reinterpret_cast<half_t*>(mp.e4) + (size_t)grow0 * (2 * C4_CH)};
-        if (wave < NW4) {
+        if constexpr (SPLIT4) {
+            // the four-tile part first (it carries the E3 copy slots), the three-tile part last (behind it the next tile's conv1
+            // weights are fetched into the registers it frees)
+            if (wave & 1) {  // a = resident tile 1 alone on position tiles 0 .. 3, the pair on tiles 4 .. 6
+                SConv<C4s, void, 0, 2, 2>::template run<1>(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0, CopyRows<NW>{rl + 256, g3});
+                SConv<C4, C1, 4, 3>::run(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0);
+            } else {         // the pair on position tiles 0 .. 3, a = resident tile 0 alone on tiles 4 .. 6
+                SConv<C4, void, 0, 2, 2>::run(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0, CopyRows<NW>{rl + 256, g3});
+                SConv<C4s, C1, 4, 3>::template run<0>(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0);
+            }
+        } else if (wave < NW4) {
             L4::run(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0);
         } else {  // a quarter of the waves has no channels in conv4: they copy the flagged E3 rows out (56 two-row slots)
             sconv_load_bias<C1>(W.c1f_bias, nt0, lane, wr);
