@@ -6,7 +6,7 @@
 // Reads keep their input order; reads shorter than -l or without complete kinetics are passed through with the
 // kinetics / old MM / ML tags stripped, exactly as the reference does.
 // Two extra sub-commands need no GPU and exist for the CPU test-suite:
-//     hifimeth-hip bamcopy [-R r/w] IN.bam OUT.bam    (BGZF/BAM round trip, optionally of one rank's shard)
+//     hifimeth-hip bamcopy [-R r/w | -Q queue [-C n]] IN.bam OUT.bam    (BGZF/BAM round trip of this process's parts of the input)
 //     hifimeth-hip merge OUT.bam N                    (joins OUT.bam.shard0..N-1 written by N ranks of call / bamcopy -R)
 //     hifimeth-hip stagebench [-t N] [-R r/w] IN.bam  (host side of call without a GPU: inflate + parse + stage; JSON rate)
 //     hifimeth-hip tagtest IN.bam CALLS.bin OUT.bam   (apply hm_call_t records, read_id = record index)
@@ -16,7 +16,10 @@
 //     hifimeth-hip modlist IN.bam                     (the MM/ML parser's output per record: test seam against the
 //                                                      reference parser's fixture, tests/golden/modparse.json)
 //     hifimeth-hip thresholds < HISTOGRAMS            (the threshold resolver alone: tests/golden/pileup_thresholds.json)
+#include <fcntl.h>
 #include <sched.h>
+#include <sys/file.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -28,6 +31,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -65,6 +69,11 @@ struct Options {
     std::string in, out;
     bool help = false;
     Shard shard;
+    // -Q <file> [-C <n>]: the input is cut into n parts (by BGZF offset, like -R) that the ranks of a job PULL from a shared
+    // counter in <file> -- the work queue of the reference's workers (src/corelib/sam_batch.hpp:38-54: whoever is free takes
+    // the next reads) stretched over processes: a rank whose reads are site-rich or long takes fewer parts
+    std::string queue;
+    int chunks = 0;
 };
 
 void usage() {
@@ -82,11 +91,14 @@ void usage() {
             "               2 = fp16 weights in conv6..conv8 (|dp| <= 1e-3 mode), 3 = fp16 weights in conv2..conv8\n"
             "  -R <r/w>     this process is rank r of w: call only the r-th part of BAM (split by BGZF offset) and write\n"
             "               MOD-BAM.shard<r>; `%s merge MOD-BAM w` joins the shards in input order\n"
+            "  -Q <file>    pull the parts of BAM from the counter in <file>, shared by all ranks of the job, instead of taking the\n"
+            "               fixed part -R names; every part k is written to MOD-BAM.shard<k>; `%s merge MOD-BAM n` joins them\n"
+            "  -C <int>     number of parts for -Q (default: one per 256 MB of BAM)\n"
             "  -z <0-9>     output compression level (default 6)\n"
             "  -S <int>     bases per engine slab (pipeline granularity, default 12582912; results do not depend on it)\n"
             "  -T <0|1>     conv1..conv4 once per site (0) / once per read position (1); default: per context, from the site\n"
             "               density of the head of BAM\n",
-            kName, kName);
+            kName, kName, kName);
 }
 
 bool parse_ctx(const char* arg, int& mask) {
@@ -177,7 +189,11 @@ bool parse(int argc, char** argv, Options& o) {
                 fprintf(stderr, "Illegal argument to option '-R' (rank/world expected)\n");
                 return false;
             }
-        } else if (a == "-h") {
+        } else if (a == "-Q") {
+            if (i + 1 >= argc) return false;
+            o.queue = argv[++i];
+        } else if (a == "-C") { if (!need(o.chunks)) return false; }
+        else if (a == "-h") {
             o.help = true;
             return false;
         } else if (a == "-v") {
@@ -196,7 +212,7 @@ bool parse(int argc, char** argv, Options& o) {
     if (o.model_dir.empty()) o.model_dir = exe_dir() + "/../weights";
     if (o.threads <= 0) o.threads = default_threads();
     if (o.read_batch < 1 || o.min_read_size < 0 || o.level < 0 || o.level > 9 || o.precision < 0 || o.precision > 3) return false;
-    if (o.slab_bases < 1 || o.trunk < -1 || o.trunk > 1) return false;
+    if (o.slab_bases < 1 || o.trunk < -1 || o.trunk > 1 || o.chunks < 0) return false;
     return true;
 }
 
@@ -221,9 +237,57 @@ std::string shard_path(const std::string& out, const Shard& sh) {
     return sh.world == 1 ? out : out + ".shard" + std::to_string(sh.rank);
 }
 
+// ---- a work queue over processes ------------------------------------------------------------------------------------------
+// The counter is a small text file; a claim is read-increment-write under an exclusive flock.  Ranks of one node (the
+// reference is a single-node program; so is a one-process-per-GPU job) share the file system, nothing else is needed.
+int claim_chunk(const std::string& path) {
+    const int fd = open(path.c_str(), O_RDWR | O_CREAT, 0644);
+    if (fd < 0) return -1;
+    int k = -1;
+    if (flock(fd, LOCK_EX) == 0) {
+        char buf[32] = {0};
+        const ssize_t n = pread(fd, buf, sizeof buf - 1, 0);
+        k = n > 0 ? atoi(buf) : 0;
+        const int len = snprintf(buf, sizeof buf, "%d\n", k + 1);
+        if (pwrite(fd, buf, (size_t)len, 0) != len || ftruncate(fd, len) != 0) k = -1;
+        flock(fd, LOCK_UN);
+    }
+    close(fd);
+    return k;
+}
+
+int default_chunks(const std::string& bam) {
+    struct stat st;
+    if (stat(bam.c_str(), &st) != 0) return 1;
+    return (int)std::max<int64_t>(1, ((int64_t)st.st_size + (int64_t(256) << 20) - 1) / (int64_t(256) << 20));
+}
+
+// The parts of the input this process handles, one after the other: the one part -R names, or whatever it can claim from
+// the queue until the counter passes the number of parts.
+struct ShardSource {
+    Shard fixed;
+    std::string queue;
+    int chunks = 0;
+    bool given = false;
+    bool next(Shard& sh) {
+        if (queue.empty()) {
+            if (given) return false;
+            given = true;
+            sh = fixed;
+            return true;
+        }
+        const int k = claim_chunk(queue);
+        if (k < 0 || k >= chunks) return false;
+        sh = Shard{k, chunks};
+        return true;
+    }
+};
+
 // reads the header (every rank needs the reference count), then positions `in` at the shard's first record;
 // end_off = compressed offset at which the next rank's records start
 bool open_shard(BgzfReader& in, const std::string& path, const Shard& sh, BamHeader& hdr, int64_t& end_off, std::string& err) {
+    if (in.block_offset() != 0 && !in.seek_block(0)) { err = in.error(); return false; }  // (a reader that has served another part)
+    hdr = BamHeader();
     if (!read_header(in, hdr, err)) return false;
     end_off = INT64_MAX;
     if (sh.world == 1) return true;
@@ -286,6 +350,10 @@ struct Job {
     hm_batch_t* batch = nullptr;
     std::vector<BamRecord> recs;
     size_t dev = 0;
+    // the part of the input this job belongs to; a job with open_part set (and no batch) starts the part's output file
+    Shard part;
+    bool open_part = false;
+    BamHeader hdr;  // open_part of part 0 only: the header to write
 };
 
 int cmd_call(int argc, char** argv) {
@@ -297,16 +365,8 @@ int cmd_call(int argc, char** argv) {
     const auto t0 = std::chrono::steady_clock::now();
     BgzfReader in(o.in, o.threads);
     if (!in.ok()) { fprintf(stderr, "[%s] %s\n", kName, in.error().c_str()); return EXIT_FAILURE; }
-    BamHeader hdr;
     std::string err;
-    int64_t end_off = 0;
-    if (!open_shard(in, o.in, o.shard, hdr, end_off, err)) { fprintf(stderr, "[%s] %s: %s\n", kName, o.in.c_str(), err.c_str()); return EXIT_FAILURE; }
-    BgzfWriter out(shard_path(o.out, o.shard), o.threads, o.level);
-    if (!out.ok()) { fprintf(stderr, "[%s] %s\n", kName, out.error().c_str()); return EXIT_FAILURE; }
-    if (o.shard.rank == 0) {
-        add_pg(hdr, argc, argv);
-        write_header(out, hdr);
-    }
+    ShardSource src{o.shard, o.queue, o.queue.empty() ? 0 : (o.chunks > 0 ? o.chunks : default_chunks(o.in))};
 
     // one engine per device, three batch slots each: one being staged, one on the GPU, one being tagged / written
     std::vector<hm_engine_t*> eng(o.devices.size(), nullptr);
@@ -324,24 +384,27 @@ int cmd_call(int argc, char** argv) {
         if (tmask < 0) { fprintf(stderr, "[%s] %s: %s\n", kName, o.in.c_str(), err.c_str()); return EXIT_FAILURE; }
         for (auto* e : eng) hm_set_option(e, "trunk_mask", tmask);
     }
-    size_t all_reads = 0, all_bases = 0, all_ctx[3] = {0, 0, 0};
+    size_t all_reads = 0, all_bases = 0, all_ctx[3] = {0, 0, 0}, all_parts = 0;
     std::atomic<bool> failed{false};
 
     // A producer thread inflates and parses batch k+1 while this thread stages batch k into a free slot of the least
     // loaded device (a pull queue: a device takes work whenever one of its slots frees up); a consumer thread collects
-    // finished batches in submission order, builds the tags on the host threads and deflates.
+    // finished batches in submission order, builds the tags on the host threads and deflates.  The pipeline runs on across
+    // the parts of the input this process takes: the consumer switches output files when a job of the next part arrives.
     struct Batch {
         std::vector<BamRecord> recs;
         bool eof = false;
         std::string err;
     };
     Batch nb[2];
+    int64_t end_off = 0;
     auto produce = [&](Batch& bt) {
         bt.recs.clear();
         bt.err.clear();
+        bt.eof = false;
         int64_t bases = 0;
         while ((int)bt.recs.size() < o.read_batch && bases < o.slab_bases) {
-            if (end_off < 0 || in.block_offset() >= end_off) { bt.eof = true; break; }  // the next record is another rank's
+            if (end_off < 0 || in.block_offset() >= end_off) { bt.eof = true; break; }  // the next record is another part's
             BamRecord r;
             if (!read_record(in, r, bt.err)) { bt.eof = true; break; }
             bases += r.l_qseq();
@@ -353,8 +416,23 @@ int cmd_call(int argc, char** argv) {
     std::deque<Job> ready;
     std::vector<int> inflight(eng.size(), 0);
     bool no_more = false;
+    std::unique_ptr<BgzfWriter> out;
+    std::string out_path;
 
+    auto close_out = [&]() {
+        if (out && !out->close()) { fprintf(stderr, "[%s] %s: %s\n", kName, out_path.c_str(), out->error().c_str()); failed = true; }
+        out.reset();
+    };
     auto finish = [&](Job& jb) {
+        if (jb.open_part) {  // the first job of a part: its output file (and, for the first part of the input, the header)
+            close_out();
+            out_path = shard_path(o.out, jb.part);
+            out.reset(new BgzfWriter(out_path, o.threads, o.level));
+            if (!out->ok()) { fprintf(stderr, "[%s] %s\n", kName, out->error().c_str()); failed = true; return; }
+            if (jb.part.rank == 0) write_header(*out, jb.hdr);
+            ++all_parts;
+            return;
+        }
         const hm_call_t* calls = nullptr;
         const int64_t got = hm_batch_wait(jb.batch, &calls);
         if (got < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(eng[jb.dev])); failed = true; return; }
@@ -382,7 +460,7 @@ int cmd_call(int argc, char** argv) {
                 return;
             }
             all_bases += (size_t)jb.recs[i].l_qseq();
-            write_record(out, jb.recs[i]);
+            write_record(*out, jb.recs[i]);
         }
         all_reads += jb.recs.size();
         fprintf(stderr, "[%s] %zu reads done\n", kName, all_reads);
@@ -399,20 +477,30 @@ int cmd_call(int argc, char** argv) {
             }
             if (!failed) finish(jb);
             if (jb.batch) hm_batch_release(jb.batch);
-            {
+            if (!jb.open_part) {
                 std::lock_guard<std::mutex> lk(mu);
                 --inflight[jb.dev];
             }
             cv.notify_all();
         }
     });
-    auto launch = [&](Job&& jb) {
-        if (hm_batch_enqueue(jb.batch) < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(eng[jb.dev])); failed = true; return; }
+    auto push = [&](Job&& jb) {
         {
             std::lock_guard<std::mutex> lk(mu);
             ready.push_back(std::move(jb));
         }
         cv.notify_all();
+    };
+    auto launch = [&](Job&& jb) {
+        if (hm_batch_enqueue(jb.batch) < 0) {
+            fprintf(stderr, "[%s] %s\n", kName, hm_last_error(eng[jb.dev]));
+            failed = true;
+            hm_batch_release(jb.batch);
+            std::lock_guard<std::mutex> lk(mu);
+            --inflight[jb.dev];
+            return;
+        }
+        push(std::move(jb));
     };
     auto begin_job = [&](Job& jb) {
         {   // the device with the fewest batches in flight; wait while every slot everywhere is taken
@@ -422,41 +510,68 @@ int cmd_call(int argc, char** argv) {
             ++inflight[jb.dev];
         }
         jb.batch = hm_batch_begin(eng[jb.dev]);
-        if (!jb.batch) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(eng[jb.dev])); failed = true; }
-    };
-    int cur = 0;
-    produce(nb[0]);
-    while (!failed) {
-        Batch& bt = nb[cur];
-        if (!bt.err.empty()) { fprintf(stderr, "[%s] %s: %s\n", kName, o.in.c_str(), bt.err.c_str()); failed = true; break; }
-        std::thread producer;
-        if (!bt.eof) producer = std::thread(produce, std::ref(nb[cur ^ 1]));
-        if (!bt.recs.empty()) {
-            Job jb;
-            begin_job(jb);
-            for (size_t i = 0; i < bt.recs.size() && !failed; ++i) {
-                BamRecord& r = bt.recs[i];
-                const KineticsView kv = kinetics_of(r);
-                int rc = hm_batch_submit_read(jb.batch, (int32_t)jb.recs.size(), r.l_qseq(), r.flag(), r.seq4(), kv.arr[0], kv.width[0],
-                                              kv.arr[1], kv.width[1], kv.arr[2], kv.width[2], kv.arr[3], kv.width[3]);
-                if (rc == HM_ENOMEM) {  // the slot is full (2^31 bases): queue it and go on in a fresh one
-                    launch(std::move(jb));
-                    jb = Job();
-                    begin_job(jb);
-                    if (failed) break;
-                    rc = hm_batch_submit_read(jb.batch, 0, r.l_qseq(), r.flag(), r.seq4(), kv.arr[0], kv.width[0], kv.arr[1],
-                                              kv.width[1], kv.arr[2], kv.width[2], kv.arr[3], kv.width[3]);
-                }
-                if (rc < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(eng[jb.dev])); failed = true; break; }
-                jb.recs.push_back(std::move(r));
-            }
-            bt.recs.clear();
-            if (!failed) launch(std::move(jb));
-            else if (jb.batch) hm_batch_release(jb.batch);
+        if (!jb.batch) {
+            fprintf(stderr, "[%s] %s\n", kName, hm_last_error(eng[jb.dev]));
+            failed = true;
+            std::lock_guard<std::mutex> lk(mu);
+            --inflight[jb.dev];
         }
-        if (producer.joinable()) producer.join();
-        if (bt.eof) break;
-        cur ^= 1;
+    };
+
+    Shard part;
+    while (!failed && src.next(part)) {
+        BamHeader hdr;
+        if (!open_shard(in, o.in, part, hdr, end_off, err)) { fprintf(stderr, "[%s] %s: %s\n", kName, o.in.c_str(), err.c_str()); failed = true; break; }
+        {
+            Job op;
+            op.part = part;
+            op.open_part = true;
+            if (part.rank == 0) {
+                add_pg(hdr, argc, argv);
+                op.hdr = hdr;
+            }
+            push(std::move(op));
+        }
+        int cur = 0;
+        produce(nb[0]);
+        while (!failed) {
+            Batch& bt = nb[cur];
+            if (!bt.err.empty()) { fprintf(stderr, "[%s] %s: %s\n", kName, o.in.c_str(), bt.err.c_str()); failed = true; break; }
+            std::thread producer;
+            if (!bt.eof) producer = std::thread(produce, std::ref(nb[cur ^ 1]));
+            if (!bt.recs.empty()) {
+                Job jb;
+                jb.part = part;
+                begin_job(jb);
+                for (size_t i = 0; i < bt.recs.size() && !failed; ++i) {
+                    BamRecord& r = bt.recs[i];
+                    const KineticsView kv = kinetics_of(r);
+                    int rc = hm_batch_submit_read(jb.batch, (int32_t)jb.recs.size(), r.l_qseq(), r.flag(), r.seq4(), kv.arr[0], kv.width[0],
+                                                  kv.arr[1], kv.width[1], kv.arr[2], kv.width[2], kv.arr[3], kv.width[3]);
+                    if (rc == HM_ENOMEM) {  // the slot is full (2^31 bases): queue it and go on in a fresh one
+                        launch(std::move(jb));
+                        jb = Job();
+                        jb.part = part;
+                        begin_job(jb);
+                        if (failed) break;
+                        rc = hm_batch_submit_read(jb.batch, 0, r.l_qseq(), r.flag(), r.seq4(), kv.arr[0], kv.width[0], kv.arr[1],
+                                                  kv.width[1], kv.arr[2], kv.width[2], kv.arr[3], kv.width[3]);
+                    }
+                    if (rc < 0) { fprintf(stderr, "[%s] %s\n", kName, hm_last_error(eng[jb.dev])); failed = true; break; }
+                    jb.recs.push_back(std::move(r));
+                }
+                bt.recs.clear();
+                if (!failed) launch(std::move(jb));
+                else if (jb.batch) {
+                    hm_batch_release(jb.batch);
+                    std::lock_guard<std::mutex> lk(mu);
+                    --inflight[jb.dev];
+                }
+            }
+            if (producer.joinable()) producer.join();
+            if (bt.eof) break;
+            cur ^= 1;
+        }
     }
     {
         std::lock_guard<std::mutex> lk(mu);
@@ -464,44 +579,57 @@ int cmd_call(int argc, char** argv) {
     }
     cv.notify_all();
     writer.join();
+    close_out();
     for (auto* e : eng) hm_destroy(e);
     if (failed) return EXIT_FAILURE;
-    if (!out.close()) { fprintf(stderr, "[%s] %s: %s\n", kName, o.out.c_str(), out.error().c_str()); return EXIT_FAILURE; }
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "******** Final stats:\n  ## Reads: %zu\n  ## Bases: %zu\n", all_reads, all_bases);
     static const char* cn[3] = {"CpG", "CHG", "CHH"};
     for (int c = 0; c < 3; ++c)
         if (all_ctx[c]) fprintf(stderr, "  ## %s samples: %zu\n", cn[c], all_ctx[c]);
+    if (!o.queue.empty()) fprintf(stderr, "  ## Parts taken from the queue: %zu of %d\n", all_parts, src.chunks);
     fprintf(stderr, "  ## Wall time: %.2f s (%.0f sites/s end to end)\n", sec, (double)(all_ctx[0] + all_ctx[1] + all_ctx[2]) / sec);
     return 0;
 }
 
-// bamcopy [-R r/w] IN.bam OUT.bam : BGZF/BAM round trip (of this rank's shard)
+// bamcopy [-R r/w | -Q queue [-C n]] IN.bam OUT.bam : BGZF/BAM round trip of the parts of the input this process takes
 int cmd_bamcopy(int argc, char** argv) {
-    Shard sh;
+    ShardSource src;
     int a = 2;
-    if (argc >= 6 && std::string(argv[2]) == "-R") {
-        if (!parse_shard(argv[3], sh)) { usage(); return EXIT_FAILURE; }
-        a = 4;
+    while (a + 1 < argc && argv[a][0] == '-') {
+        const std::string f = argv[a];
+        if (f == "-R") { if (!parse_shard(argv[a + 1], src.fixed)) { usage(); return EXIT_FAILURE; } }
+        else if (f == "-Q") src.queue = argv[a + 1];
+        else if (f == "-C") src.chunks = atoi(argv[a + 1]);
+        else { usage(); return EXIT_FAILURE; }
+        a += 2;
     }
     if (argc - a != 2) { usage(); return EXIT_FAILURE; }
+    if (!src.queue.empty() && src.chunks <= 0) src.chunks = default_chunks(argv[a]);
     BgzfReader in(argv[a], 4);
-    BamHeader h;
-    std::string err;
-    int64_t end_off = 0;
-    if (!in.ok() || !open_shard(in, argv[a], sh, h, end_off, err)) { fprintf(stderr, "%s%s\n", in.error().c_str(), err.c_str()); return EXIT_FAILURE; }
-    BgzfWriter out(shard_path(argv[a + 1], sh), 4, 6);
-    if (!out.ok()) return EXIT_FAILURE;
-    if (sh.rank == 0) write_header(out, h);
-    BamRecord r;
-    size_t n = 0;
-    while (end_off >= 0 && in.block_offset() < end_off && read_record(in, r, err)) {
-        write_record(out, r);
-        ++n;
+    if (!in.ok()) { fprintf(stderr, "%s\n", in.error().c_str()); return EXIT_FAILURE; }
+    Shard sh;
+    size_t parts = 0, n = 0;
+    while (src.next(sh)) {
+        BamHeader h;
+        std::string err;
+        int64_t end_off = 0;
+        if (!open_shard(in, argv[a], sh, h, end_off, err)) { fprintf(stderr, "%s%s\n", in.error().c_str(), err.c_str()); return EXIT_FAILURE; }
+        BgzfWriter out(shard_path(argv[a + 1], sh), 4, 6);
+        if (!out.ok()) return EXIT_FAILURE;
+        if (sh.rank == 0) write_header(out, h);
+        BamRecord r;
+        while (end_off >= 0 && in.block_offset() < end_off && read_record(in, r, err)) {
+            write_record(out, r);
+            ++n;
+        }
+        if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return EXIT_FAILURE; }
+        if (!out.close()) return EXIT_FAILURE;
+        ++parts;
     }
-    if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return EXIT_FAILURE; }
-    fprintf(stderr, "[%s] bamcopy: rank %d/%d wrote %zu records\n", kName, sh.rank, sh.world, n);
-    return out.close() ? 0 : EXIT_FAILURE;
+    if (src.queue.empty()) fprintf(stderr, "[%s] bamcopy: rank %d/%d wrote %zu records\n", kName, sh.rank, sh.world, n);
+    else fprintf(stderr, "[%s] bamcopy: took %zu of %d parts from the queue, wrote %zu records\n", kName, parts, src.chunks, n);
+    return 0;
 }
 
 // merge OUT.bam N : joins OUT.bam.shard0 .. shard<N-1> in rank order.  A BGZF file is a series of independent gzip members,

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 from conftest import ROOT, WEIGHTS
@@ -190,3 +191,72 @@ def test_call_driver_rank_that_cannot_start_its_child_fails_the_job_without_a_ha
         assert p.exitcode == 0
     rcs = dict(q.get(timeout=5) for _ in range(2))
     assert rcs[0] != 0 and rcs[1] != 0 and not os.path.exists(out)
+
+
+def _call_dist_worker(rank, world, port, src, out, extra, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.pop("HM_DIST_BACKEND", None)
+    import sys
+    sys.path.insert(0, ROOT)
+    from hifimeth_amd import call_dist
+    q.put((rank, call_dist.run(["--copy"] + extra + [src, out])))
+
+
+@pytest.mark.parametrize("mode", ["queue", "static"])
+def test_eight_rank_call_driver(tmp_path, mode):
+    """hifimeth_amd.call_dist with EIGHT ranks (gloo; `--copy`: decode + re-encode instead of the GPU), as a node of eight GPUs
+    would run it.  Default: the ranks pull the parts of the input from the shared counter (32 parts here; a fast rank takes
+    more) -- `--static`: every rank takes its one byte range.  Either way the merged output equals the single-process output,
+    in input order, and the queue file is gone afterwards."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bamutil
+    from hifimeth_amd.synth import synth_reads
+    cli = os.path.join(ROOT, "hifimeth_amd", "bin", "hifimeth-hip")
+    reads = synth_reads(150, seed=28, median_len=5000, sigma=0.5)
+    src, one, out = str(tmp_path / "in.bam"), str(tmp_path / "one.bam"), str(tmp_path / "eight.bam")
+    bamutil.reads_to_bam(src, reads, level=1)
+    subprocess.check_call([cli, "bamcopy", src, one], stderr=subprocess.DEVNULL)
+    if mode == "queue":
+        open(out + ".queue", "w").write("7\n")    # a counter left behind by a killed job: must not make the ranks skip parts
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_call_dist_worker, args=(r, 8, port, src, out, ["--static"] if mode == "static" else [], q)) for r in range(8)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(rc == 0 for _, rc in (q.get(timeout=5) for _ in range(8)))
+    assert _payload(out) == _payload(one)
+    assert not os.path.exists(out + ".queue") and not os.path.exists(out + ".shard0")
+
+
+def test_queue_parts_are_claimed_exactly_once(tmp_path):
+    """`-Q file -C n`: three processes running at the same time claim the n parts of the input from one counter file (flock):
+    every part exactly once, whoever is faster takes more; the merged parts are the input."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bamutil
+    from hifimeth_amd.synth import synth_reads
+    cli = os.path.join(ROOT, "hifimeth_amd", "bin", "hifimeth-hip")
+    reads = synth_reads(90, seed=29, median_len=6000, sigma=0.5)
+    src, one, out, qf = str(tmp_path / "in.bam"), str(tmp_path / "one.bam"), str(tmp_path / "q.bam"), str(tmp_path / "counter")
+    bamutil.reads_to_bam(src, reads, level=1)
+    subprocess.check_call([cli, "bamcopy", src, one], stderr=subprocess.DEVNULL)
+    n = 13
+    ps = [subprocess.Popen([cli, "bamcopy", "-Q", qf, "-C", str(n), src, out], stderr=subprocess.PIPE, text=True) for _ in range(3)]
+    took, wrote = [], []
+    for p in ps:
+        err = p.communicate(timeout=120)[1]
+        assert p.returncode == 0, err
+        took.append(int(err.split("took")[1].split()[0]))
+        wrote.append(int(err.split("wrote")[1].split()[0]))
+    assert sum(took) == n and sum(wrote) == len(reads)
+    assert int(open(qf).read()) == n + 3                    # every process made one claim past the end
+    subprocess.check_call([cli, "merge", out, str(n)])
+    assert _payload(out) == _payload(one)
