@@ -243,9 +243,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (fp32 mode, resident slab, windows)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI run (BAM in -> BAM out, default flags)")
     ap.add_argument("--e2e-reads", type=int, default=24000, help="reads of the synthetic BAM of the end-to-end run (24000 ~ 1.26 GB)")
-    ap.add_argument("--precision", type=int, default=1, choices=[0, 1, 2, 3],
-                    help="CNN arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA, 2 = fp16 weights in "
-                         "conv6..conv8 (holds the 1e-3 bar of configs[4]), 3 = fp16 weights in conv2..conv8 (misses it)")
+    ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
+                    help="CNN arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (e.g. front_waves=8)")
     args = ap.parse_args()
 
@@ -435,7 +434,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {0: "f32", 1: "f16x3+f32acc", 2: "f16x3+f32acc, f16 weights conv6-8", 3: "f16w/f16x2+f32acc"}[args.precision],
+            "dtype": {0: "f32", 1: "f16x3+f32acc"}[args.precision],
             "cnn_path": "dense trunk (conv1..conv4 once per read position) + per-site edge rows + tail" if trunk_ms > 0
                         else "per site (front + tail kernels)",
             "data": "synthetic",
@@ -462,7 +461,7 @@ def main():
             what = (f"(records taken from the STREAMED run of that slab: reads of trunk groups 0, {n_groups // 2} and {n_groups - 1} "
                     f"of its {n_groups} groups per context) ")
             out["cpu_baseline"], out["parity"] = cpu_baseline([(i, slabs[0][i]) for i in sample_ids], streamed,
-                                                              tol=1e-4 if args.precision <= 1 else 1e-3, what=what)
+                                                              tol=1e-4, what=what)
             out["parity"]["trunk_groups_in_slab"] = n_groups
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             # external sanity bound, DERIVED not measured: the reference README's "~2 hours on 48

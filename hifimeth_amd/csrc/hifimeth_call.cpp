@@ -87,8 +87,7 @@ void usage() {
             "  -c <list>    contexts to call: cpg,chg,chh (default all)\n"
             "  -t <int>     host threads for BGZF inflate/deflate and tag building (default: all this process is granted)\n"
             "  -d <list>    GPU ordinals, e.g. 0,1,2,3 (default 0)\n"
-            "  -p <0..3>    arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA,\n"
-            "               2 = fp16 weights in conv6..conv8 (|dp| <= 1e-3 mode), 3 = fp16 weights in conv2..conv8\n"
+            "  -p <0|1>     arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA\n"
             "  -R <r/w>     this process is rank r of w: call only the r-th part of BAM (split by BGZF offset) and write\n"
             "               MOD-BAM.shard<r>; `%s merge MOD-BAM w` joins the shards in input order\n"
             "  -Q <file>    pull the parts of BAM from the counter in <file>, shared by all ranks of the job, instead of taking the\n"
@@ -211,7 +210,7 @@ bool parse(int argc, char** argv, Options& o) {
     o.out = argv[i + 1];
     if (o.model_dir.empty()) o.model_dir = exe_dir() + "/../weights";
     if (o.threads <= 0) o.threads = default_threads();
-    if (o.read_batch < 1 || o.min_read_size < 0 || o.level < 0 || o.level > 9 || o.precision < 0 || o.precision > 3) return false;
+    if (o.read_batch < 1 || o.min_read_size < 0 || o.level < 0 || o.level > 9 || o.precision < 0 || o.precision > 1) return false;
     if (o.slab_bases < 1 || o.trunk < -1 || o.trunk > 1 || o.chunks < 0) return false;
     return true;
 }

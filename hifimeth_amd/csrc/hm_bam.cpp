@@ -593,7 +593,16 @@ bool apply_calls(BamRecord& r, const hm_call_t* calls, size_t n, bool keep_kinet
     const uint8_t* p = r.data.data() + aux0;
     const uint8_t* end = r.data.data() + r.data.size();
     AuxField f;
-    const uint8_t* mn = nullptr;  // an existing MN tag is updated, like bam_aux_update_int does
+    // MN = l_qseq (build_mod_bam.cpp:222-224, bam_aux_update_int): an EXISTING MN tag keeps its place among the tags ("This
+    // function will not change the ordering of tags in the bam record", htslib sam.h:1844-1866) and its width when the new value
+    // fits it, as an unsigned type; a new one is appended in the smallest unsigned type that holds the value
+    const uint32_t L = (uint32_t)r.l_qseq();
+    auto put_mn = [&](int min_size) {
+        const int need = L <= 0xff ? 1 : L <= 0xffff ? 2 : 4, size = std::max(need, min_size);
+        aux.insert(aux.end(), {'M', 'N', (uint8_t)(size == 1 ? 'C' : size == 2 ? 'S' : 'I')});
+        for (int k = 0; k < size; ++k) aux.push_back((uint8_t)(L >> (8 * k)));
+    };
+    bool mn_done = false;
     while (p < end) {
         const uint8_t* start = p;
         if (!next_aux(p, end, f)) {
@@ -603,13 +612,19 @@ bool apply_calls(BamRecord& r, const hm_call_t* calls, size_t n, bool keep_kinet
         const bool kin = (f.tag[0] == 'f' || f.tag[0] == 'r') && (f.tag[1] == 'i' || f.tag[1] == 'p');
         const bool oldmod = f.tag[0] == 'M' && (f.tag[1] == 'M' || f.tag[1] == 'L');
         if ((kin && !keep_kinetics) || oldmod) continue;
-        if (f.tag[0] == 'M' && f.tag[1] == 'N' && n > 0) {
-            mn = start;
-            continue;  // re-appended below with the new value
+        if (f.tag[0] == 'M' && f.tag[1] == 'N' && n > 0 && !mn_done) {
+            const char t = (char)start[2];
+            const int old = (t == 'c' || t == 'C') ? 1 : (t == 's' || t == 'S') ? 2 : (t == 'i' || t == 'I') ? 4 : 0;
+            if (old == 0) {
+                err = "existing MN tag is not of an integer type";
+                return false;
+            }
+            put_mn(old);
+            mn_done = true;
+            continue;
         }
         aux.insert(aux.end(), start, start + f.total);
     }
-    (void)mn;
     if (n > 0) {
         // 2. MM:Z  "C+m" {",delta"} ";" "G-m" {",delta"} ";"   delta = number of skipped C (G) on the forward
         //    strand since the previous call (build_mod_bam.cpp:134-168)
@@ -645,24 +660,8 @@ bool apply_calls(BamRecord& r, const hm_call_t* calls, size_t n, bool keep_kinet
         wr32(cnt, (uint32_t)n);
         aux.insert(aux.end(), cnt, cnt + 4);
         for (size_t i = 0; i < n; ++i) aux.push_back(calls[i].scaled_prob);
-        // 4. MN = l_qseq in the smallest unsigned type that holds it (bam_aux_update_int, build_mod_bam.cpp:222-224)
-        const uint32_t L = (uint32_t)r.l_qseq();
-        aux.insert(aux.end(), {'M', 'N'});
-        if (L <= 0xff) {
-            aux.push_back('C');
-            aux.push_back((uint8_t)L);
-        } else if (L <= 0xffff) {
-            aux.push_back('S');
-            uint8_t t[2];
-            wr16(t, L);
-            aux.insert(aux.end(), t, t + 2);
-        } else {
-            aux.push_back('I');
-            aux.insert(aux.end(), cnt, cnt);  // (no-op, keeps the layout explicit)
-            uint8_t t[4];
-            wr32(t, L);
-            aux.insert(aux.end(), t, t + 4);
-        }
+        // 4. MN (see above)
+        if (!mn_done) put_mn(0);
     }
     r.data.resize(aux0);
     r.data.insert(r.data.end(), aux.begin(), aux.end());

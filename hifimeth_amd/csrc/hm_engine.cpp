@@ -147,9 +147,9 @@ struct hm_engine {
     int min_read_size = 1000;  // mod_options.cpp:10
     int64_t sub_batch = 65536;
     int front_waves = 8;
-    // 0 = fp32 MFMA; 1 = split-half f16x3 MFMA with fp32 accumulate (default); 2 = 1 with plain fp16 WEIGHTS in conv6..conv8
-    // (where they hold the 1e-3 bar of BASELINE.json configs[4]); 3 = fp16 weights in conv2..conv8 (the literal configs[4]:
-    // misses its bar, kept for the record)
+    // 0 = fp32 MFMA; 1 = split-half f16x3 MFMA with fp32 accumulate (default).  (Rounds 1-2 also had 2 / 3 = plain fp16 WEIGHTS in
+    // conv6..conv8 / conv2..conv8 for BASELINE.json configs[4]: the literal configuration misses its 1e-3 bar -- 2.5e-3 -- and the
+    // part that holds it bought nothing; closed in round 3, see README "configs[4]" and profiles/r02_term_error_table.txt.)
     int precision = 1;
     int max_slots = 3;  // batch slots of the asynchronous API (the legacy calls use one more, slot 0)
     // conv1..conv4: 1 = once per read position (dense trunk, hm_trunk.hip), 0 = once per site (front kernels), 2 = per
@@ -321,7 +321,7 @@ void launch_cnn_pair(hm_engine* e, std::vector<TimedSpan>* spans, int ctx, const
         Span sp(e, spans, K_FRONT, ctx, sr.off, sr.cap);
         if (e->precision >= 1)
             launch_front_h(e->stream, dm.k1, sr, reads, bases, kin, windows, dm.w, e->d_act4.as<float>(), e->num_cu, dbg,
-                           dbg_layer, e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr, e->precision == 3);
+                           dbg_layer, e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr, false);
         else
             launch_front(e->stream, dm.k1, sr, reads, bases, kin, windows, dm.w, e->d_act4.as<float>(), e->num_cu, dbg,
                          dbg_layer, e->front_waves, e->stamps_on ? e->d_stamps.as<unsigned long long>() : nullptr);
@@ -331,8 +331,7 @@ void launch_cnn_pair(hm_engine* e, std::vector<TimedSpan>* spans, int ctx, const
     {
         Span sp(e, spans, K_TAIL, ctx, sr.off, sr.cap);
         if (e->precision >= 1)
-            launch_tail_h(e->stream, e->d_act4.as<float>(), sr, dm.w, logits, p, ml, e->num_cu, dbg, dbg_layer,
-                          e->precision - 1);
+            launch_tail_h(e->stream, e->d_act4.as<float>(), sr, dm.w, logits, p, ml, e->num_cu, dbg, dbg_layer, 0);
         else
             launch_tail(e->stream, e->d_act4.as<float>(), sr, dm.w, logits, p, ml, e->num_cu, dbg, dbg_layer);
         sp.end();
@@ -523,7 +522,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
         e->d_zeros.reserve(1024);
         HIP_TRY(hipMemsetAsync(e->d_zeros.p, 0, 1024, e->stream));
     }
-    const bool w16 = e->precision == 3;
+    const bool w16 = false;
     const int32_t* offs = b->d_offs.as<int32_t>();
     for (const auto& g : b->groups) {
         const TrunkMaps maps{{e->d_map[0].as<uint16_t>(), e->d_map[1].as<uint16_t>(), e->d_map[2].as<uint16_t>()},
@@ -578,7 +577,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
                                          b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu);
                 else
                     launch_tail_gather(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
-                                       b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu, e->precision - 1);
+                                       b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu, 0);
                 sp.end();
             }
         }
@@ -807,8 +806,9 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
     if (k == "min_read_size") e->min_read_size = (int)value;
     else if (k == "timing") e->timing = value != 0;
     else if (k == "precision") {
-        if (value < 0 || value > 3)
-            return fail(e, HM_EINVAL, "precision must be 0 (fp32), 1 (f16x3 split), 2 (fp16 weights in conv6..conv8) or 3 (in conv2..conv8)");
+        if (value < 0 || value > 1)
+            return fail(e, HM_EINVAL, "precision must be 0 (fp32 MFMA) or 1 (split-half f16x3 MFMA, fp32 accumulate); the fp16-weight modes 2 / 3 "
+                                      "of rounds 1-2 are closed: BASELINE.json configs[4] as written misses its 1e-3 bar");
         e->precision = (int)value;
     } else if (k == "stamps") {
         e->stamps_on = value != 0;
@@ -841,6 +841,9 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
     } else if (k == "trunk_impl") {
         if (value < 0 || value > 2) return HM_EINVAL;
         e->trunk_impl = (int)value;
+    } else if (k == "num_cu") {  // workgroups per persistent launch (default: the device's CU count); experiments with engines side by side
+        if (value < 1 || value > 1024) return fail(e, HM_EINVAL, "num_cu must be 1..1024");
+        e->num_cu = (int)value;
     } else if (k == "tail_impl") {
         if (value < 0 || value > 1) return fail(e, HM_EINVAL, "tail_impl must be 0 or 1");
         e->tail_impl = (int)value;

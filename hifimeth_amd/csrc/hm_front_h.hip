@@ -840,7 +840,8 @@ void launch_tail_h(hipStream_t st, const float* act4, const SiteRange& sr, const
 #define HM_TAILA(LV)                                                                                                  \
     hipLaunchKernelGGL((tail_kernel_h<LV, false>), g, dim3(512), 0, st, act4, sr, w, logits, p, ml, dbg, dbg_layer, \
                        nullptr, nullptr, nullptr, nullptr)
-    if (w16 >= 2) HM_TAILA(2); else if (w16 == 1) HM_TAILA(1); else HM_TAILA(0);
+    (void)w16;  // (plain-fp16-weight variants W16T = 1 / 2: closed in round 3, no longer instantiated)
+    HM_TAILA(0);
 #undef HM_TAILA
 }
 
@@ -852,7 +853,8 @@ void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w
     hipLaunchKernelGGL((tail_kernel_h<LV, true>), g, dim3(512), 0, st, nullptr, sr, w, logits, p, ml, nullptr, 0,         \
                        reinterpret_cast<const half_t*>(maps.e4), reinterpret_cast<const half_t*>(edge4), e4row,          \
                        reinterpret_cast<const half_t*>(maps.zeros))
-    if (w16 >= 2) HM_TAILG(2); else if (w16 == 1) HM_TAILG(1); else HM_TAILG(0);
+    (void)w16;
+    HM_TAILG(0);
 #undef HM_TAILG
 }
 
@@ -862,16 +864,7 @@ void launch_front_h(hipStream_t st, int k1, const SiteRange& sr, const ReadDesc*
     if (sr.cap <= 0) return;
     const dim3 g(cnn_grid_h(sr, 1, grid)), b(512);
     const bool raw = windows == nullptr;
-    if (w16) {  // fp16-weights mode (conv1 and fc1 keep split weights): BASELINE.json configs[4]
-        if (k1 == 11) {
-            if (raw) hipLaunchKernelGGL((front_kernel_h<11, true, false, true>), g, b, 0, st, sr, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
-            else hipLaunchKernelGGL((front_kernel_h<11, false, false, true>), g, b, 0, st, sr, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
-        } else {
-            if (raw) hipLaunchKernelGGL((front_kernel_h<13, true, false, true>), g, b, 0, st, sr, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
-            else hipLaunchKernelGGL((front_kernel_h<13, false, false, true>), g, b, 0, st, sr, reads, bases, kin, windows, w, act4, dbg, dbg_layer, stamps);
-        }
-        return;
-    }
+    (void)w16;  // (the fp16-weights variant: closed in round 3, no longer instantiated)
 #define HM_FRONT_H(K1, RAW, ST)                                                                                  \
     hipLaunchKernelGGL((front_kernel_h<K1, RAW, ST>), g, b, 0, st, sr, reads, bases, kin, windows, w, act4, dbg, \
                        dbg_layer, stamps)

@@ -879,8 +879,8 @@ void launch_trunk(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, i
     const dim3 g(min(n_tiles * n_views, grid)), b(512);
 #define HM_TRUNK(K1, W16) \
     hipLaunchKernelGGL((trunk_kernel<K1, W16>), g, b, 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, sctx, w, maps)
-    if (k1 == 11) { if (w16) HM_TRUNK(11, true); else HM_TRUNK(11, false); }
-    else { if (w16) HM_TRUNK(13, true); else HM_TRUNK(13, false); }
+    (void)w16;  // (plain-fp16-weight variants: closed in round 3, no longer instantiated)
+    if (k1 == 11) HM_TRUNK(11, false); else HM_TRUNK(13, false);
 #undef HM_TRUNK
 }
 
@@ -894,8 +894,8 @@ void launch_trunk2(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, 
 #define HM_TRUNK(K1, W16) \
     do { if (waves8) hipLaunchKernelGGL((trunk2_kernel<K1, W16, 8>), g, b, 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, sctx, w, maps); \
          else hipLaunchKernelGGL((trunk2_kernel<K1, W16, 4>), g, b, 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, sctx, w, maps); } while (0)
-    if (k1 == 11) { if (w16) HM_TRUNK(11, true); else HM_TRUNK(11, false); }
-    else { if (w16) HM_TRUNK(13, true); else HM_TRUNK(13, false); }
+    (void)w16;
+    if (k1 == 11) HM_TRUNK(11, false); else HM_TRUNK(13, false);
 #undef HM_TRUNK
 }
 
@@ -905,8 +905,8 @@ void launch_edge(hipStream_t st, int k1, const SiteRange& sr, const RInfo* rinfo
     if (sr.cap <= 0) return;
     const dim3 g(sr.totals ? grid : max(1, min((sr.cap + EG_S - 1) / EG_S, grid))), b(512);
 #define HM_EDGE(K1, W16) hipLaunchKernelGGL((edge_kernel<K1, W16>), g, b, 0, st, sr, rinfo, bases, kin, w, maps, edge4, e4row)
-    if (k1 == 11) { if (w16) HM_EDGE(11, true); else HM_EDGE(11, false); }
-    else { if (w16) HM_EDGE(13, true); else HM_EDGE(13, false); }
+    (void)w16;
+    if (k1 == 11) HM_EDGE(11, false); else HM_EDGE(13, false);
 #undef HM_EDGE
 }
 

@@ -88,10 +88,9 @@ void hm_destroy(hm_engine_t* e);
 const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a failed hm_create */
 /* options: "slots" (batches in flight of the hm_batch_* pipeline, default 3), "min_read_size" (-l, default 1000), "timing" (0/1), "sub_batch_sites" (front/tail
  * launch granularity, default 65536), "front_waves" (4 or 8 waves per front workgroup), "precision" (0 = fp32 MFMA, exact;
- * 1 = split-half fp16x3 MFMA with fp32 accumulate (default); 2 = 1 with plain fp16 WEIGHTS in conv6..conv8, the part of the
- * network where they hold BASELINE.json configs[4]'s bar |dp| <= 1e-3 (tools/w16_error_table.py); 3 = fp16 weights in
- * conv2..conv8, the literal configs[4], which misses that bar (max |dp| ~ 2.5e-3): kept for the record; activations stay
- * split and accumulation fp32 in every mode), "trunk" (2 = per context by the site density of the FIRST batch the engine is given -- counted
+ * 1 = split-half fp16x3 MFMA with fp32 accumulate (default).  Plain fp16 WEIGHTS -- BASELINE.json configs[4] -- were options 2 / 3
+ * in rounds 1-2 and are closed: as written the configuration misses its own bar |dp| <= 1e-3 (max ~ 2.5e-3; per-term error table
+ * profiles/r02_term_error_table.txt), and the part that holds it is 1 % of the FLOPs), "trunk" (2 = per context by the site density of the FIRST batch the engine is given -- counted
  * on the host when that batch is queued and then fixed for the engine's lifetime, so the calls never depend on host timing --
  * default; 1 = conv1..conv4 once per read position; 0 = once per site; every precision has both forms), "trunk_mask" (0..7: that
  * choice made by the caller, see hm_trunk_mask_for_reads), "trunk_impl" (1 = streaming 4-wave trunk kernel,

@@ -283,11 +283,18 @@ def pileup(records, chrs, min_mapq=0, min_pi=0.0, thresholds=None):
         e[2] = motif                                  # base_motifs[soff] = motif (pileup.cpp:533-552)
         e[0 if prob >= thr[motif] else 1] += 1
     loci = sorted((sid, soff, e[0], e[1], e[2]) for (sid, soff), e in cov.items())
+    bed = bed_text([(chrs[sid][0], soff, p, n, motif) for sid, soff, p, n, motif in loci])
+    return dict(bins=bins, thresholds=thr, records=allrec, loci=loci, bed=bed)
+
+
+def bed_text(loci):
+    """(chromosome name, offset, pcov, ncov, motif) in output order -> the text of the three *.cov.bed files (pileup.cpp:562-590:
+    chr TAB k TAB k+1 TAB freq TAB pcov TAB ncov, freq = 100.0 * pcov / cov through an ostringstream = %g).  Pinned by the
+    literal rows of tests/golden/literal_pins.json."""
     bed = {"CpG": [], "CHG": [], "CHH": []}
-    for sid, soff, p, n, motif in loci:               # pileup.cpp:562-590
-        bed[("CpG", "CHG", "CHH")[motif]].append("%s\t%d\t%d\t%g\t%d\t%d\n" % (chrs[sid][0], soff, soff + 1,
-                                                                                100.0 * p / (p + n), p, n))
-    return dict(bins=bins, thresholds=thr, records=allrec, loci=loci, bed={k: "".join(v) for k, v in bed.items()})
+    for name, soff, p, n, motif in loci:
+        bed[("CpG", "CHG", "CHH")[motif]].append("%s\t%d\t%d\t%g\t%d\t%d\n" % (name, soff, soff + 1, 100.0 * p / (p + n), p, n))
+    return {k: "".join(v) for k, v in bed.items()}
 
 
 # ---- helpers: cov2bed (src/app/hifimeth/cov_to_bed.cpp) ---------------------------------------------------------

@@ -140,6 +140,95 @@ def test_tag_writer_literal_known_answers(tmp_path):
         assert d["MM"][2] == c["MM"] and d["ML"][2].tolist() == c["ML"] and d["MN"][2] == c["MN"], c["name"]
 
 
+def _literal_pins():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "literal_pins.json")))
+
+
+def test_tag_strip_rules_and_mn_literal_known_answers(tmp_path):
+    """tests/golden/literal_pins.json, tag_strip: which tags `call` removes, keeps and adds, IN WHICH ORDER, and how MN is typed --
+    written by hand from build_mod_bam.cpp:87-109,125-130,176-224 and htslib's documented bam_aux_update_* semantics (the
+    reference calls htslib inline here and holds no fixtures): fi/ri/fp/rp go unless -k, old MM / ML always go, MM / ML are
+    appended, MN = l_qseq is appended -- or, if the read already carries one, updated where it stands, as wide as it was if
+    the value fits -- and a read without calls gets the stripping only."""
+    from hifimeth_amd.synth import read_from_ascii
+    rng = np.random.default_rng(3)
+    cases = _literal_pins()["tag_strip"]
+
+    def aux_of(spec, L):
+        out = b""
+        for t in spec:
+            name, _, rest = t.partition(":")
+            typ, _, val = rest.partition("=")
+            if typ == "i":
+                out += bamutil.aux_i(name, int(val or 11))
+            elif typ == "f":
+                out += bamutil.aux_f(name, 0.5)
+            elif typ == "Z":
+                out += bamutil.aux_Z(name, val or "x")
+            elif typ == "C":
+                out += name.encode() + b"C" + bytes([int(val)])
+            elif typ == "BC":
+                out += bamutil.aux_B(name, np.full(int(val), 7, np.uint8) if val else rng.integers(0, 255, L).astype(np.uint8))
+            else:
+                raise AssertionError(t)
+        return out
+
+    for keep in (False, True):
+        sub = [c for c in cases if c["keep_kinetics"] == keep]
+        reads, calls = [], []
+        for i, c in enumerate(sub):
+            L = c["l_qseq"]
+            seq = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), L).tobytes())
+            rd = read_from_ascii(seq, None, None, None, None, name=c["name"])
+            reads.append(rd)
+            if c["calls"]:
+                cpos = [k for k, b in enumerate(seq) if b == ord("C")][:3]
+                rec = np.zeros(len(cpos), CALL_DTYPE)
+                for j, q in enumerate(cpos):
+                    rec[j] = (i, q, 0, 0, 100 + j, 0, 0.4)
+                calls.append(rec)
+        src, dst, cb = str(tmp_path / f"in{keep}.bam"), str(tmp_path / f"out{keep}.bam"), str(tmp_path / f"calls{keep}.bin")
+        # records carry exactly the fixture's tags, in the fixture's order
+        parts = [b"BAM\1" + (0).to_bytes(4, "little") + (0).to_bytes(4, "little")]
+        for c, rd in zip(sub, reads):
+            parts.append(bamutil.record(rd.name, rd.flag, rd.seq4, rd.l_qseq, aux_of(c["in"], rd.l_qseq)))
+        bamutil.write_bgzf(src, b"".join(parts))
+        np.concatenate(calls).tofile(cb)
+        subprocess.check_call([CLI, "tagtest", src, cb, dst] + (["-k"] if keep else []))
+        _, recs = bamutil.read_bam(dst)
+        for c, rec in zip(sub, recs):
+            tags = bamutil.parse_aux(rec["aux"])
+            assert [f"{t[0]}:{t[1]}" for t in tags] == c["out"], (c["name"], [f"{t[0]}:{t[1]}" for t in tags])
+            mn = [t[2] for t in tags if t[0] == "MN"]
+            assert (mn[0] if mn else None) == c["MN"], c["name"]
+
+
+def test_bed_rows_literal_known_answers():
+    """tests/golden/literal_pins.json, bed_rows: the text of a *.cov.bed row, by hand from pileup.cpp:562-590 (an ostringstream's
+    default floating-point format): the oracle's rows and the host mirror's must be these strings (the CLI's rows are compared
+    with the oracle's byte for byte in tests/test_gpu_pileup.py)."""
+    from hifimeth_amd.pileup import LOCUS_DTYPE, MethylationPileup
+    from oracle import pileup_oracle as P
+    rows = _literal_pins()["bed_rows"]
+    for r in rows:
+        assert "%s\t%d\t%d\t%g\t%d\t%d\n" % (r["chr"], r["k"], r["k"] + 1, 100.0 * r["pcov"] / (r["pcov"] + r["ncov"]), r["pcov"], r["ncov"]) == r["row"]
+    # the oracle's BED writer on a genome / call set built to produce exactly these loci
+    names = sorted({r["chr"] for r in rows}, key=[r["chr"] for r in rows].index)
+    text = P.bed_text([(r["chr"], r["k"], r["pcov"], r["ncov"], 0) for r in rows])["CpG"]
+    assert text == "".join(r["row"] for r in rows)
+    # the host mirror formats loci the same way (no device needed: bed() is pure formatting)
+    pu = MethylationPileup.__new__(MethylationPileup)
+    lens = {n: max(r["k"] for r in rows if r["chr"] == n) + 2 for n in names}
+    pu.names = names
+    pu.offsets = np.concatenate([[0], np.cumsum([lens[n] for n in names])]).astype(np.int64)
+    loci = np.zeros(len(rows), LOCUS_DTYPE)
+    for i, r in enumerate(rows):
+        loci[i]["gpos"] = pu.offsets[names.index(r["chr"])] + r["k"]
+        loci[i]["pcov"], loci[i]["ncov"], loci[i]["motif"] = r["pcov"], r["ncov"], 0
+    assert pu.bed(loci)["CpG"] == "".join(r["row"] for r in rows)
+
+
 def test_tag_writer_rejects_unsorted_calls(tmp_path, oracle, oracle_models):
     reads = _reads()
     calls = _oracle_calls(oracle, oracle_models, reads)
