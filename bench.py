@@ -423,6 +423,8 @@ def main():
         gpu_ms["edge_ms"] = sum(tm["edge_ms"])
         gpu_ms["tail_ms"] = sum(tm["tail_ms"])
         gpu_ms["empty_launches"] = tm["empty_launches"]
+        gpu_ms["trunk_launches"] = list(tm["trunk_launches"])          # per context (CpG, CHG: one strand view; CHH: two)
+        gpu_ms["trunk_positions"] = list(tm["trunk_positions"])        # view positions the trunk launches covered, per context
         out = {
             "metric": "cytosine sites/sec (CpG+CHG+CHH)",
             "value": sites_all / dt_max,
