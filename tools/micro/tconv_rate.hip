@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     unsigned long long t0, t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int it = 0; it < iters; ++it) {
-        TC::run(h0, l0, W, bias, col, EpiT{h1, l1});
+        TC::run(h0, l0, W, (const float*)bias, col, EpiT{h1, l1});
         __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
