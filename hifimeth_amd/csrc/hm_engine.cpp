@@ -159,6 +159,7 @@ struct hm_engine {
     // CpG-poor genomes.  Both paths give the same calls to within fp32 re-association.
     int trunk = 2;
     int trunk_impl = 1;  // 1: streaming 4-wave trunk kernel (hm_convs.h), 2: the same on 8 waves, 0: the 8-wave ConvH form
+    int edge_impl = 1;   // dense-trunk path, precision 1: 1 = edge2_kernel (hm_edge2.hip), 0 = edge_kernel (hm_trunk.hip); bit-identical
     int tail_impl = 1;   // dense-trunk path, precision 1: 1 = tail with resident weights (hm_tail_r.hip), 0 = tail_kernel_h (streams them per pass)
     // trunk = 2 is decided ONCE per engine, from the reads of the first non-empty batch that is queued (counted on the
     // host, estimate_density): the choice must not depend on which batches happen to have finished when the next one is
@@ -566,8 +567,12 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
             }
             {
                 Span sp(e, spans, K_EDGE, c);
-                launch_edge(e->stream, dm.k1, sr, b->d_rinfo.as<RInfo>(), b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), dm.w,
-                            maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(), e->num_cu, w16);
+                if (e->edge_impl == 1)
+                    launch_edge2(e->stream, dm.k1, sr, b->d_rinfo.as<RInfo>(), b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), dm.w,
+                                 maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(), e->num_cu);
+                else
+                    launch_edge(e->stream, dm.k1, sr, b->d_rinfo.as<RInfo>(), b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), dm.w,
+                                maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(), e->num_cu, w16);
                 sp.end();
             }
             {
@@ -844,6 +849,9 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
     } else if (k == "num_cu") {  // workgroups per persistent launch (default: the device's CU count); experiments with engines side by side
         if (value < 1 || value > 1024) return fail(e, HM_EINVAL, "num_cu must be 1..1024");
         e->num_cu = (int)value;
+    } else if (k == "edge_impl") {
+        if (value < 0 || value > 1) return fail(e, HM_EINVAL, "edge_impl must be 0 or 1");
+        e->edge_impl = (int)value;
     } else if (k == "tail_impl") {
         if (value < 0 || value > 1) return fail(e, HM_EINVAL, "tail_impl must be 0 or 1");
         e->tail_impl = (int)value;

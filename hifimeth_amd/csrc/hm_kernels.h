@@ -69,6 +69,10 @@ void launch_trunk(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, i
 void launch_edge(hipStream_t st, int k1, const SiteRange& sr, const RInfo* rinfo, const uint8_t* bases,
                  const uint32_t* kin, const CtxWeights& w, const TrunkMaps& maps, uint16_t* edge4, int32_t* e4row, int grid,
                  bool w16);
+// the same edge rows with taps read in place, zero taps skipped and map rows / weights streamed a layer ahead (hm_edge2.hip):
+// bit-identical results
+void launch_edge2(hipStream_t st, int k1, const SiteRange& sr, const RInfo* rinfo, const uint8_t* bases, const uint32_t* kin,
+                  const CtxWeights& w, const TrunkMaps& maps, uint16_t* edge4, int32_t* e4row, int grid);
 void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
                         const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, int w16_level);
 // the same tail with conv5..conv7's weights resident in registers (hm_tail_r.hip): bit-identical results

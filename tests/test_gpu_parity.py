@@ -562,6 +562,29 @@ def test_streaming_trunk_is_byte_identical_to_the_8_wave_form():
     assert out[0].tobytes() == out[1].tobytes() == out[2].tobytes()
 
 
+def test_edge2_is_byte_identical_to_the_staging_edge_kernel():
+    """Engine option edge_impl: edge2_kernel (hm_edge2.hip: taps read in place, taps on the zero padding skipped, map rows by
+    LDS-DMA and weights a layer ahead) keeps every accumulator's order of products over its live k-blocks, and the blocks it
+    skips were exact zeros: its edge rows, hence the calls, are byte-identical to edge_kernel's -- for site counts that are no
+    multiple of 32, lists shorter than the grid (one read, CpG only), both K1 geometries (CpG / CHG: 11, CHH: 13), sites whose
+    windows hang over the read's ends, and many trunk groups."""
+    from hifimeth_amd import MethylationCaller
+    reads = _mixed_reads() + synth_reads(8, seed=79, median_len=6000, sigma=0.5, frac_wide=0.3)
+    cases = [("cpg,chg,chh", reads, None), ("cpg,chg,chh", reads[:1], None), ("cpg", reads[:3], None), ("chg", reads, None), ("chh", reads, 32768)]
+    for spec, rs, group_bases in cases:
+        out = []
+        for impl in (0, 1):
+            with MethylationCaller(contexts=spec, device=0, timing=True) as m:
+                m.set_option("trunk", 1)
+                m.set_option("edge_impl", impl)
+                if group_bases:
+                    m.set_option("group_bases", group_bases)
+                out.append(m.call(rs).copy())
+                out.append(m.call(rs).copy())      # a second batch through the same engine (buffers reused)
+        assert len(out[0]) == len(out[2]) > 50, (spec, len(out[0]))
+        assert out[0].tobytes() == out[1].tobytes() == out[2].tobytes() == out[3].tobytes(), spec
+
+
 def test_resident_tail_is_byte_identical_to_the_streaming_tail():
     """Engine option tail_impl: the tail with conv5..conv7's weights resident in registers (hm_tail_r.hip: four waves, the
     6 x 7 tile pairs of conv5 dealt as pairs + singles, row-aligned LDS-DMA gather through a per-pass row table, conv5 in two
