@@ -384,7 +384,6 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
         desc_c();
         desc_d(s0, sinfo2[0]);
         load_head1(h1);
-        e2_for<0, 12>([&](auto k_) __attribute__((always_inline)) { load_kb(L2t{}, k_, lw); });
         __syncthreads();
         build_rows(sinfo2[0], tid, std::integral_constant<int, NW * 64>{}, [] {});
         e2_vmwait<0>();
@@ -409,8 +408,11 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
 #endif
         const int sn = s0 + gridDim.x * EG_S;
         desc_a(sn);
+        // conv2's weights: requested here, behind nothing but conv1's (the vector-memory path idles through conv1 otherwise)
+        e2_for<0, 12>([&](auto k_) __attribute__((always_inline)) { load_kb(L2t{}, k_, lw); });
         conv1(h1);
         ETS(1);
+        e2_vmwait<0>();
         e2_barrier();
         ETS(2);
         f32x4 acc[4];
@@ -461,19 +463,14 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
         }
         e2_barrier();
         ETS(8);
-        // ---- conv4 (96 channels = waves 0..5, which also request the next pass's conv2 map rows; the next pass's conv1 / conv2
-        // weights arrive meanwhile); waves 6 and 7 build the next pass's feature rows ----
+        // ---- conv4 (96 channels = waves 0..5, which also request the next pass's conv2 map rows and conv1 weights); waves 6 and 7
+        // build the next pass's feature rows ----
         if (wave >= C4_CH / 16) {
-            build_rows(si_next, tid - 64 * (C4_CH / 16), std::integral_constant<int, 128>{}, [&]() __attribute__((always_inline)) {
-                e2_for<0, 12>([&](auto k_) __attribute__((always_inline)) { load_kb(L2t{}, k_, lw); });
-                load_head1(h1);
-            });
+            build_rows(si_next, tid - 64 * (C4_CH / 16), std::integral_constant<int, 128>{}, [&]() __attribute__((always_inline)) { load_head1(h1); });
         } else {
-            LW ln;
             DmaSrc ds;
             constexpr int NWC = C4_CH / 16;
             layer(L4t{}, lw, mA_hi, mA_lo, acc, [&](auto k_) __attribute__((always_inline)) {
-                load_kb(L2t{}, k_, ln);
                 if constexpr (decltype(k_)::value == 11) load_head1(h1);  // (behind the layer's last free: conv1's weights are not live beside conv4's)
             }, [&](auto b_) __attribute__((always_inline)) {  // the next pass's conv2 map rows
                 constexpr int b = decltype(b_)::value, NP = (2 * E2L<K1, 2>::NI + NWC - 1) / NWC;
@@ -484,7 +481,6 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
             const EpiEdgeOut epi{reinterpret_cast<half_t*>(edge4) + (size_t)s0 * (4 * C4_CH), nullptr, nvalid};
 #pragma unroll
             for (int i = 0; i < 4; ++i) epi(i * 16 + li, wave * 16 + 4 * lk, acc[i]);
-            lw = ln;
         }
         ETS(9);
         e2_vmwait<0>();
