@@ -39,13 +39,14 @@ namespace {
 
 constexpr int E2_NW = 8;
 constexpr int E2_MROWS = 3 * EG_S;                 // rows of a map set: left chains | right chains, first map tap | second map tap
-constexpr int E2_SLACK = 256;                      // halves behind a map plane that the last DMA piece may overrun
-constexpr int E2_MPLANE = E2_MROWS * TR_RS + E2_SLACK;
+constexpr int E2_SLACK = 256;                      // halves behind a map set that the last DMA piece may overrun
+constexpr int E2_MRS = 264;                        // halves per map-set row: [hi 128 | lo 128 | 16 B pad] as the row lies in HBM (conflict-free reads)
+constexpr int E2_MSET = E2_MROWS * E2_MRS + E2_SLACK;
 constexpr int E2_SPLANE = EG_M * TR_RS;
 constexpr int E2_XRS = EG_XROWS * TR_WRS + 8;        // halves per pseudo-row of feature rows: 16 rows of 8 halves + 16 B pad (conflict-free reads)
 constexpr int E2_XH = EG_M * E2_XRS;
 constexpr int E2_AHEAD = 2;                        // k-blocks of register slack: the next layer's k-block kb is requested once kb - 2 is dead
-static_assert(TR_RS * 2 == 17 * 16, "a plane row is 17 sixteen-byte chunks (16 + pad)");
+static_assert(E2_MRS * 2 == 33 * 16, "a map-set row is 33 sixteen-byte chunks (32 + pad)");
 
 template <int I, int N, class F>
 __device__ __forceinline__ void e2_for(F&& f) {
@@ -75,7 +76,7 @@ struct E2L {
     static constexpr int R = LAYER == 2 ? G::R1 : LAYER == 3 ? G::R2 : G::R3, STEP = LAYER == 2 ? 2 : LAYER == 3 ? 4 : 8;
     static constexpr int COUT = LAYER == 4 ? C4_CH : 128;
     static constexpr int ROWS = PAD ? 2 * EG_S : 3 * EG_S;         // map rows per pass
-    static constexpr int NI = (ROWS * 17 + 63) / 64;                // DMA pieces (1 KB of LDS each) per plane
+    static constexpr int NI = (ROWS * 33 + 63) / 64;                // DMA pieces (1 KB of LDS each) per map set
     // tap kinds as in tap_source (hm_edge.h): side 0 = (zero, previous output, map); side 1 = (map, previous output, zero) or
     // (map, map, previous output)
     static constexpr int kind(int side, int tap) {
@@ -123,10 +124,10 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
     constexpr int NW = E2_NW;
     const Site* sites;
     const int n_sites = resolve_sites(sr, sites);
-    __shared__ __attribute__((aligned(16))) half_t smem[4 * E2_MPLANE + 2 * E2_SPLANE + E2_XH];
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * E2_MSET + 2 * E2_SPLANE + E2_XH];
     __shared__ E2Site sinfo2[2][EG_S];
-    half_t* mset = smem;                             // [set][plane][E2_MPLANE]
-    half_t* sp_hi = smem + 4 * E2_MPLANE;
+    half_t* mset = smem;                             // [set][E2_MSET]
+    half_t* sp_hi = smem + 2 * E2_MSET;
     half_t* sp_lo = sp_hi + E2_SPLANE;
     half_t* xb = sp_lo + E2_SPLANE;                  // feature rows of conv1's edge outputs: [pseudo-row][16 rows][8 halves] + pad
     if ((int)blockIdx.x * EG_S >= n_sites) return;
@@ -193,8 +194,8 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
             *reinterpret_cast<uint4*>(xb + row * E2_XRS + (t0 + u) * TR_WRS) = feature_row(live[u] ? (int)b[u] : -1, k[u], es.view);
     };
 
-    // ---- map rows of layer LAYER into map set `set`: piece w0 + nw t of both planes' pieces, t = 0 .. (LDS-DMA: 64 lanes x 16 B =
-    // 1 KB of a plane = 3.76 rows of 17 chunks; a lane's chunk 16 is the row's pad and re-reads chunk 15).  `dma_src` reads the
+    // ---- map rows of layer LAYER into map set `set`: piece w0 + nw t, t = 0 .. (LDS-DMA: 64 lanes x 16 B = 1 KB of the set = 1.94
+    // rows of 33 chunks -- a row's 512 bytes [hi | lo] as they lie in HBM + its pad, which re-reads chunk 31).  `dma_src` reads the
     // site's descriptor, `dma_issue` (a block of the MFMA stream later) forms the address and issues the piece -----------------------
     struct DmaSrc {
         int64_t vrow;
@@ -202,25 +203,23 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
     };
     auto dma_src = [&](auto ltag, const E2Site* si, const int i) __attribute__((always_inline)) {
         using L = E2L<K1, decltype(ltag)::value>;
-        const int ic = min(i, 2 * L::NI - 1);
-        const int ii = ic - (ic >= L::NI ? L::NI : 0);
-        const int row = min((ii * 64 + lane) / 17, L::ROWS - 1);
+        const int ic = min(i, L::NI - 1);
+        const int row = min((ic * 64 + lane) / 33, L::ROWS - 1);
         const E2Site* e = si + (row & (EG_S - 1));
         return DmaSrc{e->vrow, e->off};
     };
     auto dma_issue = [&](auto ltag, const DmaSrc& d, const int set, const int i) __attribute__((always_inline)) {
         using L = E2L<K1, decltype(ltag)::value>;
         const half_t* __restrict__ map = reinterpret_cast<const half_t*>(mp.e[decltype(ltag)::value - 2]);
-        if (i < 2 * L::NI) {  // wave-uniform
-            const int plane = i >= L::NI, ii = i - plane * L::NI;
-            const int c = ii * 64 + lane;
-            int row = c / 17;
-            const int ch = min(c - 17 * row, 15);
+        if (i < L::NI) {  // wave-uniform
+            const int c = i * 64 + lane;
+            int row = c / 33;
+            const int ch = min(c - 33 * row, 31);
             row = min(row, L::ROWS - 1);
             const int j = row >> 5;
             const int delta = j == 0 ? G::LEFT : L::R + (j - 1) * L::STEP;
-            const half_t* src = map + (size_t)(d.vrow + d.off + delta) * 256 + plane * 128 + ch * 8;
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_mset + (uint32_t)(((set * 2 + plane) * E2_MPLANE) * 2 + ii * 1024));
+            const half_t* src = map + (size_t)(d.vrow + d.off + delta) * 256 + ch * 8;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_mset + (uint32_t)((set * E2_MSET) * 2 + i * 1024));
             uint32_t km;
             asm volatile(
                 "s_mov_b32 %0, m0\n\t"
@@ -237,7 +236,7 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
         using L = E2L<K1, decltype(ltag)::value>;
         constexpr int nw = decltype(nw_)::value;
 #pragma unroll
-        for (int t = 0; t < (2 * L::NI + nw - 1) / nw; ++t) dma_issue(ltag, dma_src(ltag, si, w0 + nw * t), set, w0 + nw * t);
+        for (int t = 0; t < (L::NI + nw - 1) / nw; ++t) dma_issue(ltag, dma_src(ltag, si, w0 + nw * t), set, w0 + nw * t);
     };
     using L2t = std::integral_constant<int, 2>;
     using L3t = std::integral_constant<int, 3>;
@@ -312,26 +311,30 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
     };
     // one layer on this wave's n-tile.  `slide(kb)` is called when the registers of k-block kb - E2_AHEAD are free: the caller
     // requests the NEXT layer's k-block kb there.  `job(b)` is called once per block (the DMA pieces ride there).
-    auto layer = [&](auto ltag, const LW& lw, const half_t* mx_hi, const half_t* mx_lo, f32x4 (&acc)[4], auto slide, auto job) __attribute__((always_inline)) {
+    auto layer = [&](auto ltag, const LW& lw, const half_t* mx, f32x4 (&acc)[4], auto slide, auto job) __attribute__((always_inline)) {
         constexpr int LAYER = decltype(ltag)::value;
         using L = E2L<K1, LAYER>;
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = f32x4{lw.bz.x, lw.bz.y, lw.bz.z, lw.bz.w};
-        const int a0 = li * TR_RS + 8 * lk;  // this lane's row of m-tile 0, its 8 K elements of a 32-channel block
+        const int a0 = li * TR_RS + 8 * lk;  // this lane's row of m-tile 0, its 8 K elements of a 32-channel block (previous layer's planes)
+        const int am = li * E2_MRS + 8 * lk; // the same in a map set (rows of [hi | lo | pad])
         constexpr int LA = 2, NX = LA + 1;  // operand blocks requested ahead of the MFMAs / ring slots
         half8 x[NX][2][2];
         auto reads = [&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value, side = L::side_of(b), kb = L::kb_of(b), tap = kb / 4, q = kb % 4;
             constexpr int kind = L::kind(side, tap);
             static_assert(kind != SRC_ZERO, "live taps only");
-            constexpr int row0 = kind == SRC_MAP ? 32 * L::map_j(side, tap) : 0;
-            const half_t* p_hi = kind == SRC_MAP ? mx_hi : sp_hi;
-            const half_t* p_lo = kind == SRC_MAP ? mx_lo : sp_lo;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int o = a0 + ((2 * side + i) * 16 + row0) * TR_RS + 32 * q;
-                x[b % NX][i][0] = *reinterpret_cast<const half8*>(p_hi + o);
-                x[b % NX][i][1] = *reinterpret_cast<const half8*>(p_lo + o);
+                if constexpr (kind == SRC_MAP) {
+                    const int o = am + ((2 * side + i) * 16 + 32 * L::map_j(side, tap)) * E2_MRS + 32 * q;
+                    x[b % NX][i][0] = *reinterpret_cast<const half8*>(mx + o);
+                    x[b % NX][i][1] = *reinterpret_cast<const half8*>(mx + o + 128);
+                } else {
+                    const int o = a0 + ((2 * side + i) * 16) * TR_RS + 32 * q;
+                    x[b % NX][i][0] = *reinterpret_cast<const half8*>(sp_hi + o);
+                    x[b % NX][i][1] = *reinterpret_cast<const half8*>(sp_lo + o);
+                }
             }
         };
         e2_for<0, E2_AHEAD>(slide);
@@ -394,10 +397,8 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
     for (int s0 = blockIdx.x * EG_S; s0 < n_sites; s0 += gridDim.x * EG_S) {
         const int nvalid = min(EG_S, n_sites - s0);
         const E2Site* si_next = sinfo2[cur ^ 1];
-        const half_t* mA_hi = mset + (size_t)(sel * 2) * E2_MPLANE;          // conv2 and conv4 read this set, conv3 the other
-        const half_t* mA_lo = mA_hi + E2_MPLANE;
-        const half_t* mB_hi = mset + (size_t)((sel ^ 1) * 2) * E2_MPLANE;
-        const half_t* mB_lo = mB_hi + E2_MPLANE;
+        const half_t* mA = mset + (size_t)sel * E2_MSET;          // conv2 and conv4 read this set, conv3 the other
+        const half_t* mB = mset + (size_t)(sel ^ 1) * E2_MSET;
         tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lk = lane >> 4;
@@ -421,9 +422,9 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
         {
             LW ln;
             DmaSrc ds;
-            layer(L2t{}, lw, mA_hi, mA_lo, acc, [&](auto k_) __attribute__((always_inline)) { load_kb(L3t{}, k_, ln); },
+            layer(L2t{}, lw, mA, acc, [&](auto k_) __attribute__((always_inline)) { load_kb(L3t{}, k_, ln); },
                   [&](auto b_) __attribute__((always_inline)) {  // conv3's map rows: a piece per block, its descriptor read a block earlier
-                      constexpr int b = decltype(b_)::value, NP = (2 * E2L<K1, 3>::NI + NW - 1) / NW;
+                      constexpr int b = decltype(b_)::value, NP = (E2L<K1, 3>::NI + NW - 1) / NW;
                       static_assert(NP < E2L<K1, 2>::NB, "the pieces fit the layer's blocks");
                       if constexpr (b >= 1 && b - 1 < NP) dma_issue(L3t{}, ds, sel ^ 1, wave + NW * (b - 1));
                       if constexpr (b < NP) ds = dma_src(L3t{}, sinfo2[cur], wave + NW * b);
@@ -444,9 +445,9 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
         {
             LW ln;
             DmaSrc ds;
-            layer(L3t{}, lw, mB_hi, mB_lo, acc, [&](auto k_) __attribute__((always_inline)) { load_kb(L4t{}, k_, ln); },
+            layer(L3t{}, lw, mB, acc, [&](auto k_) __attribute__((always_inline)) { load_kb(L4t{}, k_, ln); },
                   [&](auto b_) __attribute__((always_inline)) {  // conv4's map rows
-                      constexpr int b = decltype(b_)::value, NP = (2 * E2L<K1, 4>::NI + NW - 1) / NW;
+                      constexpr int b = decltype(b_)::value, NP = (E2L<K1, 4>::NI + NW - 1) / NW;
                       static_assert(NP < E2L<K1, 3>::NB, "the pieces fit the layer's blocks");
                       if constexpr (b >= 1 && b - 1 < NP) dma_issue(L4t{}, ds, sel, wave + NW * (b - 1));
                       if constexpr (b < NP) ds = dma_src(L4t{}, sinfo2[cur], wave + NW * b);
@@ -470,10 +471,10 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
         } else {
             DmaSrc ds;
             constexpr int NWC = C4_CH / 16;
-            layer(L4t{}, lw, mA_hi, mA_lo, acc, [&](auto k_) __attribute__((always_inline)) {
+            layer(L4t{}, lw, mA, acc, [&](auto k_) __attribute__((always_inline)) {
                 if constexpr (decltype(k_)::value == 11) load_head1(h1);  // (behind the layer's last free: conv1's weights are not live beside conv4's)
             }, [&](auto b_) __attribute__((always_inline)) {  // the next pass's conv2 map rows
-                constexpr int b = decltype(b_)::value, NP = (2 * E2L<K1, 2>::NI + NWC - 1) / NWC;
+                constexpr int b = decltype(b_)::value, NP = (E2L<K1, 2>::NI + NWC - 1) / NWC;
                 static_assert(NP < E2L<K1, 4>::NB, "the pieces fit the layer's blocks");
                 if constexpr (b >= 1 && b - 1 < NP) dma_issue(L2t{}, ds, sel ^ 1, wave + NWC * (b - 1));
                 if constexpr (b < NP) ds = dma_src(L2t{}, si_next, wave + NWC * b);

@@ -94,8 +94,9 @@ const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a fa
  * on the host when that batch is queued and then fixed for the engine's lifetime, so the calls never depend on host timing --
  * default; 1 = conv1..conv4 once per read position; 0 = once per site; every precision has both forms), "trunk_mask" (0..7: that
  * choice made by the caller, see hm_trunk_mask_for_reads), "trunk_impl" (1 = streaming 4-wave trunk kernel,
- * default; 2 = the same on 8 waves; 0 = the 8-wave ConvH form; byte-identical results), "group_bases" (reads per trunk group, default 2 Mi bases),
- * "stamps" (diagnostic) */
+ * default; 2 = the same on 8 waves; 0 = the 8-wave ConvH form; byte-identical results), "edge_impl" (1 = edge2_kernel, default; 0 = round 2's
+ * edge_kernel; byte-identical), "tail_impl" (1 = tail with register-resident weights, default; 0 = the streaming tail; byte-identical),
+ * "group_bases" (reads per trunk group, default 2 Mi bases), "num_cu" (workgroups of the persistent kernels), "stamps" (diagnostic) */
 int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
 
 /* ---- staging: the EvalKmerFeaturesGenerator::init seam ----------------------------------- */
