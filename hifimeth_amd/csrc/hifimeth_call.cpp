@@ -2,7 +2,7 @@
 // Keeps the reference's `hifimeth call` surface (src/app/hifimeth/mod_options.cpp:61-181, mod_main.cpp:303-412):
 //     hifimeth-hip call [-m dir] [-l 1000] [-s 32] [-b 10000] [-k] [-c cpg,chg,chh] [-t N] [-d 0,1,..] BAM MOD-BAM
 // -b keeps the reference's meaning and default (reads per outer batch); it does NOT set the granularity of the GPU pipeline:
-// batches are cut into engine slabs of <= 12 Mi bases (-S), so the default flags run the pipeline at full depth.
+// batches are cut into engine slabs of <= 6 Mi bases (-S), so the default flags run the pipeline at full depth.
 // Reads keep their input order; reads shorter than -l or without complete kinetics are passed through with the
 // kinetics / old MM / ML tags stripped, exactly as the reference does.
 // Two extra sub-commands need no GPU and exist for the CPU test-suite:
@@ -62,8 +62,9 @@ struct Options {
     int precision = 1;
     // reads are handed to the engine in slabs of at most this many bases, whatever -b says: -b is the reference's outer
     // batch (mod_options.cpp:13), the slab is the granularity of THIS pipeline (decode | stage | GPU | tag + write overlap
-    // slab by slab).  12 Mi bases = six trunk groups, ~50 ms of device time.
-    int64_t slab_bases = int64_t(12) << 20;
+    // slab by slab).  6 Mi bases = three trunk groups, ~25 ms of device time; measured end to end on a 1.26 GB file: 2 Mi 2.7 s,
+    // 4 - 8 Mi 2.55 s, 12 Mi 2.8 s, 24 Mi 3.1 s (smaller: launch tails; larger: the pipeline fills and drains slab by slab).
+    int64_t slab_bases = int64_t(6) << 20;
     int trunk = -1;  // -1: chosen per context from the head of the input file (the same on every rank); 0 / 1: forced
     std::vector<int> devices{0};
     std::string in, out;
@@ -94,7 +95,7 @@ void usage() {
             "               fixed part -R names; every part k is written to MOD-BAM.shard<k>; `%s merge MOD-BAM n` joins them\n"
             "  -C <int>     number of parts for -Q (default: one per 256 MB of BAM)\n"
             "  -z <0-9>     output compression level (default 6)\n"
-            "  -S <int>     bases per engine slab (pipeline granularity, default 12582912; results do not depend on it)\n"
+            "  -S <int>     bases per engine slab (pipeline granularity, default 6291456; results do not depend on it)\n"
             "  -T <0|1>     conv1..conv4 once per site (0) / once per read position (1); default: per context, from the site\n"
             "               density of the head of BAM\n",
             kName, kName, kName);

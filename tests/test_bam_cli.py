@@ -292,7 +292,7 @@ def test_cli_call_sharded_over_ranks_matches_single_rank(tmp_path):
 @pytest.mark.gpu
 def test_cli_default_flags_cut_batches_into_slabs_without_changing_the_output(tmp_path):
     """`-b` keeps the reference's meaning (reads per outer batch, default 10000: mod_options.cpp:10-17) but no longer sets the
-    granularity of the GPU pipeline: a batch is cut into engine slabs of <= 12 Mi bases (-S).  2 000 reads (~30 Mbases) with
+    granularity of the GPU pipeline: a batch is cut into engine slabs of <= 6 Mi bases (-S).  2 000 reads (~30 Mbases) with
     the default flags, with -b 250 and with tiny slabs must give byte-identical BAM payloads -- the calls do not depend
     on the batch cut (mod_main.cpp:330-362) -- and the default run must have used more than one slab."""
     import gzip
