@@ -236,7 +236,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=11600,
+    ap.add_argument("--reads", type=int, default=11700,
                     help="reads per slab = per step (~15 kb each); default: 20 steps cover BASELINE.json configs[2] (~1.1 G sites)")
     ap.add_argument("--pool", type=int, default=6, help="distinct slabs synthesised up front; steps cycle through them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
