@@ -104,7 +104,7 @@ def cpu_baseline(sample, gpu_calls=None, budget_s=25.0, tol=1e-4, what=""):
     return out, parity
 
 
-GROUP_BASES = 2 << 20   # engine default `group_bases`: reads per trunk group (hm_engine.cpp, stage_read)
+GROUP_BASES = 16 << 20   # engine default `group_bases`: reads per trunk group (hm_engine.cpp, stage_read); --opt group_bases=N follows
 
 
 def trunk_groups(reads):
@@ -232,6 +232,7 @@ def stream(mc, slabs, order, keep=None):
 
 
 def main():
+    global GROUP_BASES
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -272,6 +273,8 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         mc.set_option(k, int(v))
+        if k == "group_bases":
+            GROUP_BASES = int(v)
 
     def barrier():
         if dist is not None:

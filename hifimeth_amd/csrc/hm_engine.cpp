@@ -165,7 +165,9 @@ struct hm_engine {
     // host, estimate_density): the choice must not depend on which batches happen to have finished when the next one is
     // queued -- the two paths differ by fp32 re-association (~1e-5 in p), and the reference's output is deterministic.
     int trunk_mask_auto = -1;  // contexts that take the dense trunk under trunk = 2 (-1: not decided yet); guarded by mu
-    int64_t group_bases = int64_t(2) << 20;  // reads per trunk group: their maps take ~3.9 KB per base
+    // reads per trunk group: their maps take ~3.9 KB per base (16 Mi bases: 64 GB of the 288).  Larger groups = fewer launches of the
+    // resident-weight kernels, which load their weights once per launch: streamed bench 56.5 M sites/s at 2 Mi, 57.7 M at 16 Mi, 56.4 M at 32 Mi
+    int64_t group_bases = int64_t(16) << 20;
     bool stamps_on = false;
     std::vector<unsigned long long> stamp_sum;
     bool timing = false;

@@ -96,7 +96,7 @@ const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a fa
  * choice made by the caller, see hm_trunk_mask_for_reads), "trunk_impl" (1 = streaming 4-wave trunk kernel,
  * default; 2 = the same on 8 waves; 0 = the 8-wave ConvH form; byte-identical results), "edge_impl" (1 = edge2_kernel, default; 0 = round 2's
  * edge_kernel; byte-identical), "tail_impl" (1 = tail with register-resident weights, default; 0 = the streaming tail; byte-identical),
- * "group_bases" (reads per trunk group, default 2 Mi bases), "num_cu" (workgroups of the persistent kernels), "stamps" (diagnostic) */
+ * "group_bases" (reads per trunk group, default 16 Mi bases: their maps take 3.9 KB of HBM per base), "num_cu" (workgroups of the persistent kernels), "stamps" (diagnostic) */
 int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
 
 /* ---- staging: the EvalKmerFeaturesGenerator::init seam ----------------------------------- */
