@@ -154,6 +154,9 @@ struct TConv {
         auto reads = [&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value, g = b / KB, kb = b % KB, s0 = slot_base(b);
             const int off = C::lane_off(kb, lk);
+#ifdef HM_ABL_NOREAD   // tools/micro ablation: operands stay what the first block read
+            if constexpr (b >= NG * 0 + issued(0)) return;
+#endif
 #pragma unroll
             for (int i = 0; i < nts[g]; ++i) {
                 x[(s0 + 2 * i) % NS] = *reinterpret_cast<const half8*>(in_hi + aoff[tile_base(g) + i] + off);
@@ -171,7 +174,11 @@ struct TConv {
                 col = m < RM::M ? col : Epi::PADCOL;
                 m = m < RM::M ? m : RM::M - 1;
             }
+#ifdef HM_ABL_NOEPI    // tools/micro ablation: the accumulator is kept alive, nothing is computed or stored from it
+            { const f32x4 keep = acc[g & 1][a]; asm volatile("" ::"v"(keep)); }
+#else
             epi(m, col, acc[g & 1][a]);
+#endif
         };
         tstatic_for<0, issued(0)>(reads);
 
