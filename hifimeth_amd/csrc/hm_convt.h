@@ -70,18 +70,17 @@ __device__ __forceinline__ void tw_load(const half_t* __restrict__ wfrag, const 
         }
 }
 
-// One group of a wave's schedule: GP m-tiles from TP on which BOTH resident n-tiles run (a pair: the two share the activation
-// reads) and GS m-tiles from TS on which only resident n-tile 0 runs.  A group's 2 GP + GS accumulators are visited round-robin,
-// product by product.  (How many accumulators a group has does not set its rate: a chain of v_mfma_f32_16x16x32_f16 onto ONE
-// accumulator issues every 16 cycles -- tools/micro/mfma_chain.hip -- and tools/micro/tconv_rate.hip measures 23 .. 28 ticks per
-// MFMA for every shape: the stream is bound by the ~2.5 other instructions that ride with each MFMA.)
-template <int TP_, int GP_, int TS_, int GS_>
+// One group of a wave's schedule: GP m-tiles from TP on which the wave's first NJ resident n-tiles run (NJ = 2, a pair: they share
+// the activation reads; NJ = 4 for fc1 in the head kernel) and GS m-tiles from TS on which only resident n-tile 0 runs.  A group's
+// NJ GP + GS accumulators are visited round-robin, product by product.  (How many accumulators a group has does not set its rate:
+// a chain of v_mfma_f32_16x16x32_f16 onto ONE accumulator issues every 16 cycles -- tools/micro/mfma_chain.hip.)
+template <int TP_, int GP_, int TS_, int GS_, int NJ_ = 2>
 struct TG {
-    static constexpr int TP = TP_, GP = GP_, TS = TS_, GS = GS_;
-    static constexpr int NT = GP_ + GS_, NA = 2 * GP_ + GS_;
+    static constexpr int TP = TP_, GP = GP_, TS = TS_, GS = GS_, NJ = NJ_;
+    static constexpr int NT = GP_ + GS_, NA = NJ_ * GP_ + GS_;
     static constexpr int tile(int i) { return i < GP_ ? TP_ + i : TS_ + (i - GP_); }   // i-th tile of the group
-    static constexpr int acc_tile(int a) { return a < 2 * GP_ ? a / 2 : GP_ + (a - 2 * GP_); }   // tile index (in the group) of accumulator a
-    static constexpr int acc_j(int a) { return a < 2 * GP_ ? a % 2 : 0; }                        // resident n-tile of accumulator a
+    static constexpr int acc_tile(int a) { return a < NJ_ * GP_ ? a / NJ_ : GP_ + (a - NJ_ * GP_); }   // tile index (in the group) of accumulator a
+    static constexpr int acc_j(int a) { return a < NJ_ * GP_ ? a % NJ_ : 0; }                          // resident n-tile of accumulator a
 };
 
 template <int I, int N, class F>
@@ -98,11 +97,21 @@ struct TNoHook {
 };
 
 // The groups run back to back as ONE stream of (group, k-block) blocks: per block 3 MFMAs per accumulator, a share of the
-// previous group's epilogue (ReLU, split, LDS stores) and `hook(block)` -- the caller's slot for work that should ride
-// between the MFMAs (the LDS-DMA gather of the next group of sites).
+// previous group's epilogue and `hook(block)` -- the caller's slot for work that should ride between the MFMAs (the LDS-DMA
+// gather of the next group of sites).
 // Activation operands come through a RING of NS half8 registers: a block's reads are issued as early as the ring has room
 // for them, at most LA blocks ahead.
-// Epi: epi(m, col, acc).  ncol[j]: first channel of the wave's resident n-tile j.
+//
+// Epilogue (round 4).  tools/micro/tconv_ablate.hip showed that round 3's epilogue -- 26 vector instructions + 2 LDS stores per
+// accumulator tile, all of a tile's inside ONE k-block, 3-4 per MFMA -- was not hidden at all: it cost its full issue time, 17 % of
+// a call (an MFMA 16x16x32 holds the issue port 8 of its 16 cycles: two 4-cycle instructions per MFMA are free, the third is
+// not).  Now (a) the rows a tile's results go to are computed ONCE per tile in the prologue, together with the operand rows
+// (one division per tile instead of one per tile and one per accumulator), (b) an accumulator's epilogue is two STAGES --
+// compute (ReLU, split) and store -- that ride in different k-blocks, and (c) a block's vector instructions are dealt evenly
+// over ALL its MFMAs.
+// Epi: struct St; row(site, p, m) -> offset of the output row; s0(acc, St&) compute; s1(off, col, St&) stores; NV0 / NV1 = vector
+// instructions the scheduler sees in the two stages, NW = stores of stage 1, WMASK = their scheduling class (0x200 LDS store,
+// 0x040 vector-memory store).  ncol[j]: first channel of resident n-tile j.
 template <class C, class RM, int NS, int LA, class... GR>
 struct TConv {
     static constexpr int NG = sizeof...(GR);
@@ -139,23 +148,33 @@ struct TConv {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));  // keep this layer's address arithmetic inside the pass loop
         const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
-        int aoff[NTILES];  // per tile of the schedule: this lane's first row in the input planes
-        tstatic_for<0, NG>([&](auto g_) __attribute__((always_inline)) {
+        // per tile of the schedule: this lane's first row in the input planes and the row its results go to (Epi's units).  Only the
+        // first group's are computed here; a later group's ride between the MFMAs of the group before it (they are needed when
+        // that group's last blocks prefetch) -- less prologue in front of the first MFMA, fewer registers live across the call
+        int aoff[NTILES];
+        int ooff[NTILES];
+        auto tile_addr = [&](auto g_) __attribute__((always_inline)) {
             constexpr int g = decltype(g_)::value;
             using G = Grp<g>;
             tstatic_for<0, G::NT>([&](auto i_) __attribute__((always_inline)) {
-                constexpr int i = decltype(i_)::value;
-                aoff[tile_base(g) + i] = RM::template off<C>(G::tile(i) * 16 + li);
+                constexpr int i = decltype(i_)::value, tile = G::tile(i);
+                int m = tile * 16 + li;
+                if constexpr ((tile + 1) * 16 > RM::M) m = m < RM::M ? m : RM::M - 1;  // ragged last tile: re-read the last valid row
+                const int site = m / RM::LOUT, p = m - site * RM::LOUT;
+                aoff[tile_base(g) + i] = site * RM::ISS + 2 * p * C::IRS;
+                ooff[tile_base(g) + i] = Epi::row(site, p, m);
             });
-        });
+        };
+        tile_addr(std::integral_constant<int, 0>{});
         f32x4 acc[2][AMAX];
         half8 x[NS];
+        typename Epi::St est[AMAX];
 
         auto reads = [&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value, g = b / KB, kb = b % KB, s0 = slot_base(b);
             const int off = C::lane_off(kb, lk);
-#ifdef HM_ABL_NOREAD   // tools/micro ablation: operands stay what the first block read
-            if constexpr (b >= NG * 0 + issued(0)) return;
+#ifdef HM_ABL_NOREAD   // tools/micro ablation: operands stay what the first blocks read
+            if constexpr (b >= issued(0)) return;
 #endif
 #pragma unroll
             for (int i = 0; i < nts[g]; ++i) {
@@ -163,21 +182,23 @@ struct TConv {
                 x[(s0 + 2 * i + 1) % NS] = *reinterpret_cast<const half8*>(in_lo + aoff[tile_base(g) + i] + off);
             }
         };
-        auto epilogue = [&](auto g_, auto a_) __attribute__((always_inline)) {
-            constexpr int g = decltype(g_)::value, a = decltype(a_)::value;
+        // stage s of accumulator a of group g
+        auto stage = [&](auto g_, auto a_, auto s_) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_)::value, a = decltype(a_)::value, st = decltype(s_)::value;
             using G = Grp<g>;
-            constexpr int tile = G::tile(G::acc_tile(a)), j = G::acc_j(a);
-            int m = tile * 16 + li, col = ncol[j] + 4 * lk;
-            if constexpr ((tile + 1) * 16 > RM::M) {
+            constexpr int ti = G::acc_tile(a), tile = G::tile(ti), j = G::acc_j(a);
+#ifdef HM_ABL_NOEPI    // tools/micro ablation: the accumulator is kept alive, nothing is computed or stored from it
+            if constexpr (st == 0) { const f32x4 keep = acc[g & 1][a]; asm volatile("" ::"v"(keep)); }
+#else
+            if constexpr (st == 0) {
+                epi.s0(acc[g & 1][a], est[a]);
+            } else {
+                int col = ncol[j] + 4 * lk;
                 // ragged last tile: rows past M write their (meaningless) values into the 16-byte pad behind the channels
                 // of the last valid row instead of being branched around -- a branch here would cut the block in two
-                col = m < RM::M ? col : Epi::PADCOL;
-                m = m < RM::M ? m : RM::M - 1;
+                if constexpr ((tile + 1) * 16 > RM::M) col = tile * 16 + li < RM::M ? col : Epi::PADCOL;
+                epi.s1(ooff[tile_base(g) + ti], col, est[a]);
             }
-#ifdef HM_ABL_NOEPI    // tools/micro ablation: the accumulator is kept alive, nothing is computed or stored from it
-            { const f32x4 keep = acc[g & 1][a]; asm volatile("" ::"v"(keep)); }
-#else
-            epi(m, col, acc[g & 1][a]);
 #endif
         };
         tstatic_for<0, issued(0)>(reads);
@@ -187,18 +208,18 @@ struct TConv {
             using G = Grp<g>;
             if constexpr (kb == 0) {
                 float4 bz[WT::NTR];
-                if constexpr (std::is_pointer_v<Bias>) {
-                    bz[0] = *reinterpret_cast<const float4*>(bias + ncol[0] + 4 * lk);
-                    if constexpr (G::GP > 0) bz[WT::NTR - 1] = *reinterpret_cast<const float4*>(bias + ncol[WT::NTR - 1] + 4 * lk);
-                } else {
-                    bz[0] = bias(0);
-                    if constexpr (G::GP > 0) bz[WT::NTR - 1] = bias(WT::NTR - 1);
+                constexpr int NBZ = G::GP > 0 ? G::NJ : 1;  // resident n-tiles this group uses
+#pragma unroll
+                for (int j = 0; j < NBZ; ++j) {
+                    if constexpr (std::is_pointer_v<Bias>) bz[j] = *reinterpret_cast<const float4*>(bias + ncol[j] + 4 * lk);
+                    else bz[j] = bias(j);
                 }
                 tstatic_for<0, G::NA>([&](auto a_) __attribute__((always_inline)) {
                     constexpr int a = decltype(a_)::value, j = G::acc_j(a);
                     acc[g & 1][a] = f32x4{bz[j].x, bz[j].y, bz[j].z, bz[j].w};
                 });
             }
+            if constexpr (kb == 0 && g + 1 < NG) tile_addr(std::integral_constant<int, (g + 1 < NG ? g + 1 : 0)>{});
             constexpr int P0 = issued(c > 0 ? c - 1 : 0), P1 = issued(c);
             if constexpr (c > 0) tstatic_for<P0, P1>(reads);
             // product-major over the group's accumulators: an accumulator is revisited NA MFMAs later
@@ -210,33 +231,117 @@ struct TConv {
                                                                            acc[g & 1][a], 0, 0, 0);
                 });
             });
-            // the previous group's accumulators leave between this group's MFMAs, spread over its k-blocks
-            constexpr int NAP = g > 0 ? nas[g > 0 ? g - 1 : 0] : 0;
-            constexpr int A0 = kb * NAP / KB, A1 = (kb + 1) * NAP / KB;
+            // the previous group's accumulators leave between this group's MFMAs: 2 stages each, dealt over its k-blocks
+            constexpr int NAP = g > 0 ? nas[g > 0 ? g - 1 : 0] : 0, NST = 2 * NAP;
+            constexpr int E0 = kb * NST / KB, E1 = (kb + 1) * NST / KB;
             if constexpr (g > 0)
-                tstatic_for<A0, A1>([&](auto a_) __attribute__((always_inline)) { epilogue(std::integral_constant<int, (g > 0 ? g - 1 : 0)>{}, a_); });
+                tstatic_for<E0, E1>([&](auto e_) __attribute__((always_inline)) {
+                    constexpr int e = decltype(e_)::value;
+                    stage(std::integral_constant<int, (g > 0 ? g - 1 : 0)>{}, std::integral_constant<int, e / 2>{}, std::integral_constant<int, e % 2>{});
+                });
             hook(c_);
-            {   // interleave plan: this step's LDS reads behind the first MFMAs, epilogue VALU + its LDS stores behind the rest
+            {   // interleave plan: this step's LDS reads behind the first MFMAs, the stages' vector instructions dealt over all MFMAs,
+                // their LDS stores behind the last ones
                 constexpr int NRD = [&]() constexpr { int n = 0; for (int b = (c > 0 ? P0 : P1); b < P1; ++b) n += nreads(b); return n; }();
-                constexpr int ND = NRD + (kb == 0 && std::is_pointer_v<Bias> ? (G::GP > 0 ? 2 : 1) : 0) + HDS;
+                constexpr int ND = NRD + (kb == 0 && std::is_pointer_v<Bias> ? (G::GP > 0 ? G::NJ : 1) : 0) + HDS;
                 constexpr int NM = 3 * G::NA;
-                constexpr int NR = NM > ND ? NM - ND : 1;
-                constexpr int NV = ((A1 - A0) * 26 + NR - 1) / NR;
-#pragma unroll
-                for (int q = 0; q < (ND < NM ? ND : NM); ++q) {
+                constexpr int NVA = kb == 0 && g + 1 < NG ? 9 * nts[g + 1 < NG ? g + 1 : 0] : 0;  // the next group's row offsets
+                constexpr int NV = NVA + [&]() constexpr { int n = 0; for (int e = E0; e < E1; ++e) n += e % 2 == 0 ? Epi::NV0 : Epi::NV1; return g > 0 ? n : 0; }();
+                constexpr int NWR = [&]() constexpr { int n = 0; for (int e = E0; e < E1; ++e) n += e % 2 == 1 ? Epi::NW : 0; return g > 0 ? n : 0; }();
+                tstatic_for<0, NM>([&](auto q_) __attribute__((always_inline)) {
+                    constexpr int q = decltype(q_)::value;
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-#pragma unroll
-                for (int q = 0; q < NM - ND; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
-                    if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                }
+                    if constexpr (q < ND) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    constexpr int nv = (q + 1) * NV / NM - q * NV / NM;
+                    if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
+                    if constexpr (q >= NM - NWR) __builtin_amdgcn_sched_group_barrier(Epi::WMASK, 1, 0);
+                });
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        tstatic_for<0, nas[NG - 1]>([&](auto a_) __attribute__((always_inline)) { epilogue(std::integral_constant<int, NG - 1>{}, a_); });
+        // the last group's accumulators: nothing to hide behind -- stage-major, so that the tiles' dependent chains (accumulator
+        // read, ReLU, convert, residual, store) overlap each other
+        tstatic_for<0, nas[NG - 1]>([&](auto a_) __attribute__((always_inline)) { stage(std::integral_constant<int, NG - 1>{}, a_, std::integral_constant<int, 0>{}); });
+        tstatic_for<0, nas[NG - 1]>([&](auto a_) __attribute__((always_inline)) { stage(std::integral_constant<int, NG - 1>{}, a_, std::integral_constant<int, 1>{}); });
+    }
+};
+
+// LDS-only barrier: orders this workgroup's LDS traffic, leaves vector-memory operations (the gather) in flight
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// s_waitcnt vmcnt(0) as a BUILTIN (simm16: vmcnt 0, expcnt 7, lgkmcnt 15 = no wait): the compiler's own wait-count bookkeeping
+// sees it.  Written as inline asm it would not -- the weights requested before the pass loop would still count as pending in
+// the compiler's model, and the waits it then places in front of their first uses INSIDE the loop would, in steady state,
+// wait for whatever is in flight there: the gather.
+__device__ __forceinline__ void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// s_waitcnt vmcnt(N): all but the wave's N youngest vector-memory operations (loads, stores, LDS-DMAs alike, in issue order) are done
+template <int N>
+__device__ __forceinline__ void e2_vmwait_n() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+// Epilogue functors for TConv (hm_convt.h): an accumulator tile leaves in two stages -- s0 computes (ReLU, hi / lo split),
+// s1 stores -- to a row whose offset row(site, p, m) TConv computes once per tile.  NV0 / NV1: vector instructions of the two
+// stages that the scheduler's interleave plan counts (split_lo2 is inline asm: not counted), NW: LDS stores of s1.
+// ReLU + split -> planes of S stacked sites, physical row p + 1 (row 0 of a site is zero padding)
+template <int LOUT, int ORS, int OSS>
+struct EpiStack {
+    static constexpr int PADCOL = ORS - 8;  // the 16-byte pad behind a row's channels: where a ragged tile's surplus rows write
+    static constexpr int NV0 = 6, NV1 = 1, NW = 2, WMASK = 0x200;
+    struct St { half4 h, l; };
+    half_t* hi;
+    half_t* lo;
+    static __device__ __forceinline__ int row(int site, int p, int) { return site * OSS + (p + 1) * ORS; }
+    __device__ __forceinline__ void s0(const f32x4& acc, St& s) const { split4(acc, s.h, s.l); }
+    __device__ __forceinline__ void s1(int off, int col, const St& s) const {
+        *reinterpret_cast<half4*>(hi + off + col) = s.h;
+        *reinterpret_cast<half4*>(lo + off + col) = s.l;
+    }
+};
+// conv8's output for the batched fc1: rows 0..LOUT-1 of a site back to back
+template <int ORS>
+struct EpiRows {
+    static constexpr int PADCOL = ORS - 8;
+    static constexpr int NV0 = 6, NV1 = 1, NW = 2, WMASK = 0x200;
+    struct St { half4 h, l; };
+    half_t* hi;
+    half_t* lo;
+    static __device__ __forceinline__ int row(int, int, int m) { return m * ORS; }
+    __device__ __forceinline__ void s0(const f32x4& acc, St& s) const { split4(acc, s.h, s.l); }
+    __device__ __forceinline__ void s1(int off, int col, const St& s) const {
+        *reinterpret_cast<half4*>(hi + off + col) = s.h;
+        *reinterpret_cast<half4*>(lo + off + col) = s.l;
+    }
+};
+template <int HRS>
+struct EpiFc1R {  // ReLU, fp32 h[site][256] for the VALU fc2
+    static constexpr int PADCOL = 0;
+    static constexpr int NV0 = 4, NV1 = 1, NW = 1, WMASK = 0x200;
+    struct St { float4 v; };
+    float* out;
+    static __device__ __forceinline__ int row(int, int, int m) { return m * HRS; }
+    __device__ __forceinline__ void s0(const f32x4& acc, St& s) const { s.v = make_float4(relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3])); }
+    __device__ __forceinline__ void s1(int off, int col, const St& s) const { *reinterpret_cast<float4*>(out + off + col) = s.v; }
+};
+
+// the same ReLU + split, straight to global memory: conv6's rows in the split tail (hm_tail_s.hip) leave the chip as the planes
+// the head kernel's flat LDS-DMA expects: [site][LOUT + 2 rows][ORS halves] per plane, padding rows and columns never written
+template <int LOUT, int ORS, int OSS>
+struct EpiGStack {
+    static constexpr int PADCOL = ORS - 8;
+    static constexpr int NV0 = 6, NV1 = 1, NW = 2, WMASK = 0x040;
+    struct St { half4 h, l; };
+    half_t* __restrict__ hi;   // this pass's first site in the hi plane (wave-uniform)
+    half_t* __restrict__ lo;
+    static __device__ __forceinline__ int row(int site, int p, int) { return site * OSS + (p + 1) * ORS; }
+    __device__ __forceinline__ void s0(const f32x4& acc, St& s) const { split4(acc, s.h, s.l); }
+    __device__ __forceinline__ void s1(int off, int col, const St& s) const {
+        *reinterpret_cast<half4*>(hi + (unsigned)(off + col)) = s.h;
+        *reinterpret_cast<half4*>(lo + (unsigned)(off + col)) = s.l;
     }
 };
 

@@ -160,7 +160,10 @@ struct hm_engine {
     int trunk = 2;
     int trunk_impl = 1;  // 1: streaming 4-wave trunk kernel (hm_convs.h), 2: the same on 8 waves, 0: the 8-wave ConvH form
     int edge_impl = 1;   // dense-trunk path, precision 1: 1 = edge2_kernel (hm_edge2.hip), 0 = edge_kernel (hm_trunk.hip); bit-identical
-    int tail_impl = 1;   // dense-trunk path, precision 1: 1 = tail with resident weights (hm_tail_r.hip), 0 = tail_kernel_h (streams them per pass)
+    // dense-trunk path, precision 1: 2 = the split tail (hm_tail_s.hip: conv5 + conv6, then conv7 .. softmax batched over 16 sites),
+    // 1 = one kernel with resident weights (hm_tail_r.hip), 0 = tail_kernel_h (streams them per pass); bit-identical
+    int tail_impl = 2;
+    int64_t tail_slice = int64_t(1) << 21;  // sites per launch pair of the split tail: its hand-off buffer holds 7.5 KB per site
     // trunk = 2 is decided ONCE per engine, from the reads of the first non-empty batch that is queued (counted on the
     // host, estimate_density): the choice must not depend on which batches happen to have finished when the next one is
     // queued -- the two paths differ by fp32 re-association (~1e-5 in p), and the reference's output is deterministic.
@@ -183,6 +186,8 @@ struct hm_engine {
     // scratch shared by all batches: only touched by kernels on the compute stream, which runs batches in order
     DevBuf d_act4, d_win, d_dbg, d_stamps;
     DevBuf d_map[3], d_e4, d_edge4, d_e4row, d_zeros, d_rowlist;  // dense trunk: maps of one read group, edge rows of its sites
+    DevBuf d_x6;                // split tail: conv6's rows of one launch (hm_tail_s.hip)
+    int64_t x6_sites = 0;       // the site count d_x6's plane stride was laid out for
 
     std::vector<hipEvent_t> pool;
     hm_timing_t acc{};
@@ -579,7 +584,25 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
             }
             {
                 Span sp(e, spans, K_TAILG, c);
-                if (e->tail_impl == 1 && e->precision == 1)
+                if (e->tail_impl == 2 && e->precision == 1) {
+                    // launches of at most tail_slice sites: the hand-off buffer is laid out (and zeroed: its padding rows are never
+                    // written) once, for the largest launch seen
+                    const int64_t slice = std::min<int64_t>(e->tail_slice, std::max<int64_t>(max_bases, 1));
+                    if (slice > e->x6_sites) {
+                        e->d_x6.reserve(tail_split_x6_bytes(slice));
+                        HIP_TRY(hipMemsetAsync(e->d_x6.p, 0, tail_split_x6_bytes(slice), e->stream));
+                        e->x6_sites = slice;
+                    }
+                    const size_t ph = tail_split_x6_plane_halves(e->x6_sites);
+                    for (int64_t off = 0; off < g.bases; off += e->x6_sites) {
+                        SiteRange s2 = sr;
+                        s2.off = (int32_t)off;
+                        s2.cap = (int32_t)std::min<int64_t>(e->x6_sites, g.bases - off);
+                        launch_tail_split(e->stream, s2, dm.w, maps, e->d_edge4.as<uint16_t>() + (size_t)off * (4 * C4_CH),
+                                          e->d_e4row.as<int32_t>() + off, e->d_x6.as<uint16_t>(), ph, b->d_logits.as<float>(),
+                                          b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu);
+                    }
+                } else if (e->tail_impl == 1 && e->precision == 1)
                     launch_tail_gather_r(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
                                          b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu);
                 else
@@ -798,7 +821,7 @@ void hm_destroy(hm_engine_t* e) {
     e->slots.clear();
     for (auto& m : e->model) m.params.release();
     for (DevBuf* b : {&e->d_act4, &e->d_win, &e->d_dbg, &e->d_stamps, &e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4, &e->d_rowlist,
-                      &e->d_edge4, &e->d_e4row, &e->d_zeros})
+                      &e->d_edge4, &e->d_e4row, &e->d_zeros, &e->d_x6})
         b->release();
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -855,8 +878,11 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
         if (value < 0 || value > 1) return fail(e, HM_EINVAL, "edge_impl must be 0 or 1");
         e->edge_impl = (int)value;
     } else if (k == "tail_impl") {
-        if (value < 0 || value > 1) return fail(e, HM_EINVAL, "tail_impl must be 0 or 1");
+        if (value < 0 || value > 2) return fail(e, HM_EINVAL, "tail_impl must be 0, 1 or 2");
         e->tail_impl = (int)value;
+    } else if (k == "tail_slice") {
+        if (value < 16) return fail(e, HM_EINVAL, "tail_slice must be at least 16");
+        e->tail_slice = value;
     } else if (k == "group_bases") {
         if (value < 1) return fail(e, HM_EINVAL, "group_bases must be positive");
         e->group_bases = value;

@@ -78,6 +78,13 @@ void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w
 // the same tail with conv5..conv7's weights resident in registers (hm_tail_r.hip): bit-identical results
 void launch_tail_gather_r(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
                           const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid);
+// the tail as two kernels (hm_tail_s.hip): conv5 + conv6 (8 sites per pass, conv6's rows to `x6`), then conv7 .. softmax (16 sites per
+// pass, all weights resident): bit-identical results.  `x6`: tail_split_x6_bytes(max sites of a launch) bytes, zeroed once;
+// `x6_plane_halves` = tail_split_x6_plane_halves(that same maximum) for every launch into it.
+size_t tail_split_x6_plane_halves(int64_t sites);
+size_t tail_split_x6_bytes(int64_t sites);
+void launch_tail_split(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
+                       const int32_t* e4row, uint16_t* x6, size_t x6_plane_halves, float* logits, float* p, uint8_t* ml, int grid);
 void launch_trunk2(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,
                    const TrunkMaps& maps, int grid, bool w16, bool waves8 = false);

@@ -58,55 +58,6 @@ struct RGeo {
     static_assert((3 * 16 / L5) * IN_ROWS + 2 * (3 * 16 % L5) >= LOW_ROWS, "conv5 tiles 3..6 stay clear of the late rows");
 };
 
-// LDS-only barrier: orders this workgroup's LDS traffic, leaves vector-memory operations (the gather) in flight
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-// s_waitcnt vmcnt(0) as a BUILTIN (simm16: vmcnt 0, expcnt 7, lgkmcnt 15 = no wait): the compiler's own wait-count bookkeeping
-// sees it.  Written as inline asm it would not -- the weights requested before the pass loop would still count as pending in
-// the compiler's model, and the waits it then places in front of their first uses INSIDE the loop would, in steady state,
-// wait for whatever is in flight there: the gather.
-__device__ __forceinline__ void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
-
-// ReLU + split -> planes of S stacked sites, physical row p + 1 (row 0 of a site is zero padding)
-template <int LOUT, int ORS, int OSS>
-struct EpiStack {
-    static constexpr int PADCOL = ORS - 8;  // the 16-byte pad behind a row's channels: where a ragged tile's surplus rows write
-    half_t* hi;
-    half_t* lo;
-    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
-        const int site = m / LOUT, p = m - site * LOUT;
-        half4 h, l;
-        split4(acc, h, l);
-        *reinterpret_cast<half4*>(hi + site * OSS + (p + 1) * ORS + col) = h;
-        *reinterpret_cast<half4*>(lo + site * OSS + (p + 1) * ORS + col) = l;
-    }
-};
-// conv8's output for the batched fc1: rows 0..LOUT-1 of a site back to back
-template <int ORS>
-struct EpiRows {
-    static constexpr int PADCOL = ORS - 8;
-    half_t* hi;
-    half_t* lo;
-    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
-        half4 h, l;
-        split4(acc, h, l);
-        *reinterpret_cast<half4*>(hi + m * ORS + col) = h;
-        *reinterpret_cast<half4*>(lo + m * ORS + col) = l;
-    }
-};
-template <int HRS>
-struct EpiFc1R {  // ReLU, fp32 h[site][256] for the VALU fc2
-    static constexpr int PADCOL = 0;
-    float* out;
-    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
-        *reinterpret_cast<float4*>(out + m * HRS + col) =
-            make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
-    }
-};
-
 // zero the two padding rows (physical rows 0 and LOUT + 1) of S stacked sites, C channels, 16 bytes per store
 template <int LOUT, int C, int RS, int SS>
 __device__ __forceinline__ void zero_pads(half_t* hi, half_t* lo, int t) {
@@ -247,6 +198,7 @@ void tail_kernel_r(SiteRange sr, CtxWeights W, float* __restrict__ logits, float
     unsigned long long tts[12], tacc[12] = {};
     unsigned long long tn = 0;
     const bool tst = blockIdx.x == 0;
+    const unsigned long long tk0 = hm_stamp(), tr0 = __builtin_amdgcn_s_memrealtime();
 #define TTS(i) do { if (tst) tts[i] = hm_stamp(); } while (0)
 #else
 #define TTS(i)
@@ -375,6 +327,8 @@ void tail_kernel_r(SiteRange sr, CtxWeights W, float* __restrict__ logits, float
     if (tst && lane == 0) {
         for (int i = 0; i < 11; ++i) atomicAdd(&g_tailr_stamp[wave][i], tacc[i]);
         atomicAdd(&g_tailr_stamp[wave][11], tn);
+        atomicAdd(&g_tailr_stamp[wave][13], hm_stamp() - tk0);
+        atomicAdd(&g_tailr_stamp[wave][14], __builtin_amdgcn_s_memrealtime() - tr0);
     }
 #endif
 #undef TTS

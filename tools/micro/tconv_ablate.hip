@@ -11,12 +11,13 @@ constexpr int RS96 = 104, IN_SS = 27 * RS96, C5_SS = 15 * RS96, S = 8;
 struct EpiT {
     static constexpr int PADCOL = RS96 - 8;
     half_t* hi; half_t* lo;
-    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
-        const int site = m / 13, p = m - site * 13;
-        half4 h, l;
-        split4(acc, h, l);
-        *reinterpret_cast<half4*>(hi + site * C5_SS + (p + 1) * RS96 + col) = h;
-        *reinterpret_cast<half4*>(lo + site * C5_SS + (p + 1) * RS96 + col) = l;
+    static constexpr int NV0 = 6, NV1 = 1, NW = 2, WMASK = 0x200;
+    struct St { half4 h, l; };
+    static __device__ __forceinline__ int row(int site, int p, int) { return site * C5_SS + (p + 1) * RS96; }
+    __device__ __forceinline__ void s0(const f32x4& acc, St& s) const { split4(acc, s.h, s.l); }
+    __device__ __forceinline__ void s1(int off, int col, const St& s) const {
+        *reinterpret_cast<half4*>(hi + off + col) = s.h;
+        *reinterpret_cast<half4*>(lo + off + col) = s.l;
     }
 };
 __device__ inline unsigned hash(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }

@@ -10,7 +10,7 @@ sys.path.insert(0, ".")
 from hifimeth_amd import MethylationCaller, _lib  # noqa: E402
 from hifimeth_amd.synth import synth_reads  # noqa: E402
 
-reads = synth_reads(400, seed=5)
+reads = synth_reads(int(sys.argv[1]) if len(sys.argv) > 1 else 400, seed=5)
 mc = MethylationCaller(device=0, timing=True)
 mc.set_option("trunk", 1)
 mc.set_option("tail_impl", 1)
@@ -37,5 +37,6 @@ for i, nm in enumerate(names):
     tot += v
     print(f"{nm:30s} " + " ".join(f"{x:7.0f}" for x in v))
 print(f"{'sum':30s} " + " ".join(f"{x:7.0f}" for x in tot))
+print(f"in-kernel clock of workgroup 0's pass loops: {float(buf[0, 13]) / max(float(buf[0, 14]), 1) * 0.1:.3f} GHz (s_memtime / s_memrealtime x 100 MHz)")
 tm = mc.timing()
 print("tail_ms per run", [round(x / 3, 2) for x in tm["tail_ms"]])
