@@ -79,6 +79,7 @@ struct TrunkTile {
 
 constexpr int TR_OWN = 112;   // view positions per tile
 constexpr int TR_PAD = 200;   // the maps cover view positions [-200, len + 200)
+constexpr int TR_SLACK = 32;  // map rows of slack behind a read's tiles: the sliding-window trunk's skewed layers run up to 28 rows past the last tile
 
 struct TrunkMaps {
     uint16_t* e[3];     // E1..E3: [2 views][rows][hi 128 | lo 128] fp16 halves (only the rows an edge chain reads are written)

@@ -158,11 +158,13 @@ struct hm_engine {
     // so the trunk wins above ~1.7 % sites per base (CHH, two views: 3.3 %) -- everything but CpG-only runs on
     // CpG-poor genomes.  Both paths give the same calls to within fp32 re-association.
     int trunk = 2;
-    int trunk_impl = 1;  // 1: streaming 4-wave trunk kernel (hm_convs.h), 2: the same on 8 waves, 0: the 8-wave ConvH form
+    // 3: the streaming trunk as a sliding window (hm_trunk3.hip: 112 rows per layer and tile, 14 % fewer MFMAs), 1: streaming 4-wave trunk
+    // kernel (hm_convs.h), 2: the same on 8 waves, 0: the 8-wave ConvH form; byte-identical maps
+    int trunk_impl = 3;
     int edge_impl = 1;   // dense-trunk path, precision 1: 1 = edge2_kernel (hm_edge2.hip), 0 = edge_kernel (hm_trunk.hip); bit-identical
     // dense-trunk path, precision 1: 2 = the split tail (hm_tail_s.hip: conv5 + conv6, then conv7 .. softmax batched over 16 sites),
     // 1 = one kernel with resident weights (hm_tail_r.hip), 0 = tail_kernel_h (streams them per pass); bit-identical
-    int tail_impl = 2;
+    int tail_impl = 1;
     int64_t tail_slice = int64_t(1) << 21;  // sites per launch pair of the split tail: its hand-off buffer holds 7.5 KB per site
     // trunk = 2 is decided ONCE per engine, from the reads of the first non-empty batch that is queued (counted on the
     // host, estimate_density): the choice must not depend on which batches happen to have finished when the next one is
@@ -187,6 +189,7 @@ struct hm_engine {
     DevBuf d_act4, d_win, d_dbg, d_stamps;
     DevBuf d_map[3], d_e4, d_edge4, d_e4row, d_zeros, d_rowlist;  // dense trunk: maps of one read group, edge rows of its sites
     DevBuf d_x6;                // split tail: conv6's rows of one launch (hm_tail_s.hip)
+    DevBuf d_dump;              // sliding-window trunk: where a warm-up step's conv4 rows go (hm_trunk3.hip)
     int64_t x6_sites = 0;       // the site count d_x6's plane stride was laid out for
 
     std::vector<hipEvent_t> pool;
@@ -467,7 +470,7 @@ int stage_read(hm_batch* b, int32_t read_id, int32_t l_qseq, int32_t flag, const
         for (int t = 0; t < ntile; ++t) b->tiles.push_back(TrunkTile{ridx, -TR_PAD + t * TR_OWN});
         b->reads.push_back(rd);
         for (int st = 0; st < l_qseq; st += CHUNK) b->chunks.push_back(Chunk{ridx, st});
-        g.rows += (int64_t)ntile * TR_OWN;
+        g.rows += (int64_t)ntile * TR_OWN + TR_SLACK;
         g.bases += l_qseq;
         g.chunk_hi = (int)b->chunks.n;
         g.tile_hi = (int)b->tiles.n;
@@ -523,7 +526,8 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
     }
     for (int i = 0; i < 3; ++i) e->d_map[i].reserve((size_t)max_rows * 2 * 256 * sizeof(uint16_t));
     e->d_e4.reserve((size_t)max_rows * 2 * C4_CH * sizeof(float));
-    e->d_rowlist.reserve((size_t)(max_rows / TR_OWN + 1) * 2 * 3 * TR_OWN);
+    e->d_rowlist.reserve(std::max((size_t)(max_rows / TR_OWN + 1) * 2 * 3 * TR_OWN, trunk3_rowlist_bytes((max_rows / TR_OWN + 1) * 2)));
+    e->d_dump.reserve(trunk3_dump_bytes());
     e->d_edge4.reserve((size_t)max_bases * 2 * C4_CH * sizeof(float));
     e->d_e4row.reserve((size_t)max_bases * sizeof(int32_t));
     if (!e->d_zeros.p) {
@@ -563,7 +567,11 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
             }
             {
                 Span sp(e, spans, K_TRUNK, c, 0, (int64_t)n_tiles * TR_OWN * n_views);
-                if (e->trunk_impl)
+                if (e->trunk_impl == 3)
+                    launch_trunk3(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
+                                  b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->d_dump.as<uint16_t>(),
+                                  e->num_cu);
+                else if (e->trunk_impl)
                     launch_trunk2(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
                                   b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->num_cu, w16,
                                   e->trunk_impl == 2);
@@ -821,7 +829,7 @@ void hm_destroy(hm_engine_t* e) {
     e->slots.clear();
     for (auto& m : e->model) m.params.release();
     for (DevBuf* b : {&e->d_act4, &e->d_win, &e->d_dbg, &e->d_stamps, &e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4, &e->d_rowlist,
-                      &e->d_edge4, &e->d_e4row, &e->d_zeros, &e->d_x6})
+                      &e->d_edge4, &e->d_e4row, &e->d_zeros, &e->d_x6, &e->d_dump})
         b->release();
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -869,7 +877,7 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
         e->trunk = 2;
         e->trunk_mask_auto = (int)value & e->ctx_mask;
     } else if (k == "trunk_impl") {
-        if (value < 0 || value > 2) return HM_EINVAL;
+        if (value < 0 || value > 3) return HM_EINVAL;
         e->trunk_impl = (int)value;
     } else if (k == "num_cu") {  // workgroups per persistent launch (default: the device's CU count); experiments with engines side by side
         if (value < 1 || value > 1024) return fail(e, HM_EINVAL, "num_cu must be 1..1024");
@@ -1103,7 +1111,7 @@ int64_t hm_batch_submit_reads(hm_batch_t* b, const hm_read_t* reads, int64_t n, 
             for (int t = 0; t < ntile; ++t) b->tiles.push_back(TrunkTile{ridx, -TR_PAD + t * TR_OWN});
             b->reads.push_back(rd);
             for (int st = 0; st < r.l_qseq; st += CHUNK) b->chunks.push_back(Chunk{ridx, st});
-            g.rows += (int64_t)ntile * TR_OWN;
+            g.rows += (int64_t)ntile * TR_OWN + TR_SLACK;
             g.bases += r.l_qseq;
             g.chunk_hi = (int)b->chunks.n;
             g.tile_hi = (int)b->tiles.n;

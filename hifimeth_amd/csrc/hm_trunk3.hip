@@ -1,0 +1,320 @@
+// hm_trunk3.hip -- the dense trunk as a SLIDING WINDOW (round 4; engine option trunk_impl = 3): conv1 .. conv4 over exactly 112 rows
+// per tile and layer.
+//
+// trunk2_kernel (hm_trunk.hip) computes a tile of 112 view positions from scratch: 144 / 144 / 128 / 112 rows of conv1 .. conv4 -- the
+// halo of the dilated taps (E(l)[x] reads E(l-1)[x, x + d, x + 2 d], d = 2^(l-1), so 16 + 8 + 4 rows to the RIGHT of the tile, + K1 - 1
+// feature rows) is recomputed by the neighbour: 6 912 MFMAs per tile where 5 936 are new results, +16 %.  The kernel runs at the chip's
+// power / clock limit: its time follows the number of MFMAs it issues, not the idle cycles between them, so the halo
+// is the one lever that is worth its size.
+//
+// Here a workgroup walks a CONTIGUOUS run of tiles (consecutive tiles of a read are consecutive in the tile list) and keeps the
+// right-hand rows of every layer for the next tile: the layers of a step are SKEWED, each lagging the one below it by its halo,
+//     step at u:  E4 rows [u, u + 112)        from E3 rows [u,      u + 128) = 16 kept  + 112 new  (plane A rows 0 .. 127)
+//                 E3 rows [u + 16, u + 128)   from E2 rows [u + 16, u + 136) =  8 kept  + 112 new  (plane B rows 0 .. 119)
+//                 E2 rows [u + 24, u + 136)   from E1 rows [u + 24, u + 140) =  4 kept  + 112 new  (plane A rows 0 .. 115)
+//                 E1 rows [u + 28, u + 140)   from feature rows [u + 28, u + 152)                  (rebuilt per step: 124 rows)
+// so that every layer computes 112 rows = 7 m-tiles per step.  A plane row of a layer's input is a position, taps are rows m,
+// m + d, m + 2 d exactly as before; what changes is where a layer's output goes (behind the kept rows) and four small LDS copies
+// per step (plane A holds E1 and then E3, so E1's and E3's kept rows wait in side buffers H1 / H3 while the other uses the plane).
+// Kept rows are garbage at the start of a run (a workgroup's first tile, a read's first tile): a WARM-UP step at u - 112 comes
+// first, whose E4 rows go to a dump buffer and whose copy slots write only rows that are valid and untouched by the garbage (the
+// edge chains do read E1 .. E3 at positions -199 .. -173 of a read: those rows are new rows of the read's warm-up step).
+// Same products in the same order per accumulator as trunk2_kernel: byte-identical maps (tests/test_gpu_parity.py).
+//
+// Reference for what is computed: training/model_cnn.py:8-85 / models/*.onnx (mod_main.cpp:32-98).
+#include "hm_convh.h"
+#include "hm_convs.h"
+#include "hm_edge.h"
+
+namespace hm {
+
+namespace {
+
+constexpr int T3_M = TR_OWN;                        // rows every layer computes per step
+constexpr int T3_H1 = 4, T3_H2 = 8, T3_H3 = 16;     // rows of E1 / E2 / E3 kept for the next step (the halo of conv2 / conv3 / conv4)
+constexpr int T3_S3 = T3_H3, T3_S2 = T3_S3 + T3_H2, T3_S1 = T3_S2 + T3_H1;  // first NEW row of E3 / E2 / E1 relative to the step's u: 16, 24, 28
+constexpr int T3_AROWS = T3_M + T3_H3, T3_BROWS = T3_M + T3_H2;             // plane A: E1 (116 rows) | E3 (128 rows); plane B: E2 (120 rows)
+constexpr int T3_XROWS = 128;                       // feature rows of a step: 112 + K1 - 1 <= 124
+constexpr int T3_LDS_HALVES = 2 * T3_AROWS * TR_RS + 2 * T3_BROWS * TR_RS + 2 * (T3_H1 + T3_H3) * TR_RS;
+constexpr int T3_RL = 3 * TR_OWN;                   // bytes of a step's row lists (rowlist3_kernel)
+static_assert(T3_M % 16 == 0 && T3_RL % 4 == 0 && T3_XROWS >= T3_M + 12, "tile plan");
+
+struct EpiTrunk3 {  // ReLU + split -> LDS planes, row m of the NEW rows (the pointers are offset by the kept rows)
+    half_t* hi;
+    half_t* lo;
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        half4 h, l;
+        split4(acc, h, l);
+        *reinterpret_cast<half4*>(hi + m * TR_RS + col) = h;
+        *reinterpret_cast<half4*>(lo + m * TR_RS + col) = l;
+    }
+};
+struct EpiE43 {  // conv4 rows leave the trunk already split, [hi 96 | lo 96]
+    half_t* __restrict__ g;
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        half4 h, l;
+        split4(acc, h, l);
+        *reinterpret_cast<half4*>(g + (size_t)m * (2 * C4_CH) + col) = h;
+        *reinterpret_cast<half4*>(g + (size_t)m * (2 * C4_CH) + C4_CH + col) = l;
+    }
+};
+template <int NWV_>
+struct CopyRows3 {
+    static constexpr int NWV = NWV_, CS = TR_OWN / (2 * NWV_);  // NWV waves x 2 rows x CS slots = one list entry each
+    const uint8_t* rows;  // LDS: this layer's list of TR_OWN plane-row numbers
+    half_t* g;            // map row of plane row 0
+};
+
+// nrows whole rows (hi and lo plane) LDS -> LDS, 16 bytes per thread and round
+template <int NROWS, int NT, int K = 0>
+__device__ __forceinline__ void move_rows(half_t* dh, half_t* dl, const half_t* sh, const half_t* sl, int t) {
+    constexpr int PER = NROWS * TR_RS / 8, N = 2 * PER;  // 16-byte chunks per plane, in all
+    if constexpr (K * NT < N) {
+        const int c = min(t + K * NT, N - 1), plane = c >= PER, o = (c - plane * PER) * 8;
+        const uint4 v = *reinterpret_cast<const uint4*>((plane ? sl : sh) + o);
+        move_rows<NROWS, NT, K + 1>(dh, dl, sh, sl, t);   // (the other rounds' reads are issued before this round's store)
+        *reinterpret_cast<uint4*>((plane ? dl : dh) + o) = v;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Which map rows do the edge chains read?  Per step and layer a list of TR_OWN plane-row numbers of the layer's NEW rows: the flagged
+// ones first, the rest filled with the LAST new row (a row that is always valid and never touched by a warm-up step's garbage; storing
+// it once more is harmless).  Block w < n_work: the step of tile w; block n_work + w: the warm-up step in front of a read's first
+// tile (u - 112); block 2 n_work: the list of a warm-up step in the middle of a read (a workgroup's first tile): nothing but fill.
+template <int K1>
+__global__ __launch_bounds__(128) void rowlist3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_work, int ctx,
+                                                        const RInfo* __restrict__ rinfo, const uint8_t* __restrict__ bases,
+                                                        const uint8_t* __restrict__ sctx, uint8_t* __restrict__ rowlist) {
+    using G = EdgeGeo<K1>;
+    __shared__ int cnt0[3];
+    const int blk = blockIdx.x, r = threadIdx.x;
+    uint8_t* out = rowlist + (size_t)blk * T3_RL;
+    constexpr int first_new[3] = {T3_H1, T3_H2, T3_H3}, shift[3] = {T3_S1, T3_S2, T3_S3};
+    if (blk == 2 * n_work) {
+        for (int i = r; i < T3_RL; i += 128) out[i] = (uint8_t)(first_new[i / TR_OWN] + TR_OWN - 1);
+        return;
+    }
+    const bool warm = blk >= n_work;
+    const int w = warm ? blk - n_work : blk, view = w >= n_tiles;
+    const TrunkTile tl = tiles[view ? w - n_tiles : w];
+    if (warm && tl.u0 != -TR_PAD) return;  // (only a read's first tile has a warm-up step that stores map rows)
+    const RInfo ri = rinfo[tl.read_idx];
+    const int L = ri.len, u = tl.u0 - (warm ? TR_OWN : 0), want_base = view ? 2 : 1;
+    auto site_at = [&](int y) __attribute__((always_inline)) {
+        if (y < 0 || y >= L) return 0;
+        const int64_t j = ri.base_off + (view ? L - 1 - y : y);
+        return (int)(sctx[j] == ctx && bases[j] == want_base);
+    };
+    int f = 0;
+    if (r < TR_OWN) {
+        {
+            const int x = u + shift[0] + r;
+            f |= (site_at(x - G::LEFT) | site_at(x - G::R1) | (G::PAD2 ? 0 : site_at(x - G::R1 - 2))) << 0;
+        }
+        {
+            const int x = u + shift[1] + r;
+            f |= (site_at(x - G::LEFT) | site_at(x - G::R2) | (G::PAD3 ? 0 : site_at(x - G::R2 - 4))) << 1;
+        }
+        {
+            const int x = u + shift[2] + r;
+            f |= (site_at(x - G::LEFT) | site_at(x - G::R3) | (G::PAD4 ? 0 : site_at(x - G::R3 - 8))) << 2;
+        }
+    }
+    for (int i = r; i < T3_RL; i += 128) out[i] = (uint8_t)(first_new[i / TR_OWN] + TR_OWN - 1);
+    uint64_t bal[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) bal[l] = __ballot((f >> l) & 1);
+    if (r < 3) cnt0[r] = 0;
+    __syncthreads();  // also orders the fill before the entries below (same block, global memory)
+    if (r == 0) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) cnt0[l] = __popcll(bal[l]);
+    }
+    __syncthreads();
+    const int lane = r & 63;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+        if ((f >> l) & 1) out[l * TR_OWN + (r >= 64 ? cnt0[l] : 0) + __popcll(bal[l] & ((1ull << lane) - 1))] = (uint8_t)(first_new[l] + r);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+template <int K1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views, int ctx, const RInfo* __restrict__ rinfo,
+                   const uint8_t* __restrict__ bases, const uint32_t* __restrict__ kin, CtxWeights W, TrunkMaps mp, half_t* __restrict__ dump) {
+    constexpr int NW = 4, NTW = 2;
+    __shared__ __attribute__((aligned(16))) half_t smem[T3_LDS_HALVES + T3_XROWS * TR_WRS];
+    static_assert(sizeof(smem) == 147840, "LDS plan");
+    __shared__ uint32_t rlist[2][3 * 32];  // the step's row lists ([3][128] bytes); two buffers: conv4 still copies E3 rows while the next step's arrive
+    __shared__ int64_t s_grow0;
+    __shared__ int s_warm;
+    half_t* a_hi = smem;
+    half_t* a_lo = a_hi + T3_AROWS * TR_RS;
+    half_t* b_hi = a_lo + T3_AROWS * TR_RS;
+    half_t* b_lo = b_hi + T3_BROWS * TR_RS;
+    half_t* h1_hi = b_lo + T3_BROWS * TR_RS;   // E1's kept rows while plane A holds E3
+    half_t* h1_lo = h1_hi + T3_H1 * TR_RS;
+    half_t* h3_hi = h1_lo + T3_H1 * TR_RS;     // E3's kept rows while plane A holds E1
+    half_t* h3_lo = h3_hi + T3_H3 * TR_RS;
+    half_t* xb = h3_lo + T3_H3 * TR_RS;        // feature rows of the step (their own buffer: built while conv4 runs)
+    const int n_work = n_tiles * n_views;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // a workgroup takes a contiguous run of tiles
+    const int base_n = n_work / (int)gridDim.x, rem_n = n_work - base_n * (int)gridDim.x;
+    const int w0 = (int)blockIdx.x * base_n + min((int)blockIdx.x, rem_n), w1 = w0 + base_n + ((int)blockIdx.x < rem_n);
+    if (w0 >= w1) return;
+
+    for (int i = threadIdx.x; i < (T3_LDS_HALVES + T3_XROWS * TR_WRS) / 2; i += NW * 64) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+    if (threadIdx.x < 2 * 3 * 32) rlist[0][threadIdx.x] = 0;
+    __syncthreads();
+
+    // The next step's feature rows and row lists, one row per thread, in steps that sit between the layers so that no load's
+    // latency is exposed (as in trunk2_kernel).  The step after (w, warm-up) is (w, tile); the step after (w, tile) is (w + 1, warm-up)
+    // if tile w + 1 is a read's first, else (w + 1, tile).
+    struct Build {
+        TrunkTile tl;
+        RInfo ri;
+        int w, view, warm, ueff, b;
+        uint32_t k, rl;
+    } bd;
+    auto build_desc1 = [&](const int w) __attribute__((always_inline)) {
+        bd.w = w;
+        bd.view = w >= n_tiles;
+        bd.tl = tiles[bd.view ? w - n_tiles : w];
+    };
+    // prev_warm: the step being computed is a warm-up (then the next one is the tile itself)
+    auto build_desc2 = [&](const int prev_warm, const bool first) __attribute__((always_inline)) {
+        bd.tl.read_idx = __builtin_amdgcn_readfirstlane(bd.tl.read_idx);
+        bd.tl.u0 = __builtin_amdgcn_readfirstlane(bd.tl.u0);
+        bd.warm = first ? 1 : (prev_warm ? 0 : (bd.tl.u0 == -TR_PAD));
+        bd.ueff = bd.tl.u0 - (bd.warm ? TR_OWN : 0);
+        bd.ri = rinfo[bd.tl.read_idx];
+    };
+    auto build_desc3 = [&]() __attribute__((always_inline)) {
+        bd.ri.len = __builtin_amdgcn_readfirstlane(bd.ri.len);
+        bd.ri.map_off = __builtin_amdgcn_readfirstlane(bd.ri.map_off);
+        bd.ri.base_off = ((int64_t)__builtin_amdgcn_readfirstlane((int)(bd.ri.base_off >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)bd.ri.base_off);
+    };
+    auto build_loads = [&]() __attribute__((always_inline)) {
+        const int r = threadIdx.x, L = bd.ri.len, x = bd.ueff + T3_S1 + r;
+        const int xc = min(max(x, 0), L - 1);
+        const int64_t j = bd.ri.base_off + (bd.view ? L - 1 - xc : xc);
+        bd.b = bases[j];
+        bd.k = kin[j];
+        // the step's lists: the tile's own; a read's warm-up step's; the all-fill list of a warm-up step in the middle of a read
+        const size_t li = bd.warm ? (bd.tl.u0 == -TR_PAD ? (size_t)n_work + bd.w : (size_t)2 * n_work) : (size_t)bd.w;
+        bd.rl = reinterpret_cast<const uint32_t*>(mp.rowlist + li * T3_RL)[min(r, T3_RL / 4 - 1)];
+    };
+    auto build_store = [&](const int buf) __attribute__((always_inline)) {
+        const int r = threadIdx.x, x = bd.ueff + T3_S1 + r;
+        if (r == 0) {
+            s_grow0 = (int64_t)bd.view * mp.view_rows + bd.ri.map_off + (bd.ueff + TR_PAD);
+            s_warm = bd.warm;
+        }
+        if (r < T3_XROWS) {
+            const bool in = x >= 0 && x < bd.ri.len;
+            *reinterpret_cast<uint4*>(xb + r * TR_WRS) = feature_row(in ? bd.b : -1, bd.k, bd.view);
+        }
+        if (r < T3_RL / 4) rlist[buf][r / (TR_OWN / 4) * 32 + r % (TR_OWN / 4)] = bd.rl;
+    };
+
+    using C1 = SCfg<8, (2 * K1 + 3) / 4 * 4, TR_WRS, 1, true, false, K1, 2, NTW>;
+    using C2 = SCfg<128, 3, TR_RS, 2, true, true, 0, 1, NTW>;
+    using C3 = SCfg<128, 3, TR_RS, 4, true, true, 0, 1, NTW>;
+    using C4 = SCfg<128, 3, TR_RS, 8, true, true, 0, 1, NTW>;
+    using C4s = SCfg<128, 3, TR_RS, 8, true, true, 0, 1, 1>;   // one of the wave's two resident n-tiles alone
+    // conv4's 6 n-tiles x 7 position tiles on four waves as in trunk2_kernel: waves 0 / 2 hold (a, b) = (0, 1) / (3, 4), waves 1 / 3
+    // (b, a) = (1, 2) / (4, 5); the pair on one range of position tiles, a alone on the other
+    const int nt04 = wave == 0 ? 0 : wave == 1 ? 1 : wave == 2 ? 3 : 4;
+    using L1 = SConv<C1, C2, 0, 2, 2, 3>;
+    using L2 = SConv<C2, C3, 0, 3, 4>;  // the longest group last: it is the window in which the next layer's weights can be fetched
+    using L3 = SConv<C3, C4, 0, 3, 4>;
+    static_assert(T3_XROWS <= NW * 64, "one feature row per thread");
+    auto wf = [&](int i) { return reinterpret_cast<const half_t*>(W.wfrag_h[i]); };
+    const half_t* c1f = reinterpret_cast<const half_t*>(W.c1f);
+    const int nt0 = NTW * wave;
+
+    WRegs wr;
+    sconv_load_w<C1, 0, C1::KB>(c1f, nt0, lane, wr);
+    sconv_load_bias<C1>(W.c1f_bias, nt0, lane, wr);
+    build_desc1(w0);
+    build_desc2(0, true);
+    build_desc3();
+    build_loads();
+    build_store(0);
+    int buf = 0;
+    int w = w0, warm = 1;  // the step being computed
+    while (true) {
+        __syncthreads();  // the step's feature rows, lists and descriptors are in LDS; the previous step is through with the planes
+        const int64_t grow0 = s_grow0;
+        const int cur_warm = __builtin_amdgcn_readfirstlane(s_warm);
+        // the next step
+        const int wn = cur_warm ? w : w + 1;
+        const bool last = wn >= w1;
+        // (a read's warm-up step starts 112 rows in front of the read's region: these bases may lie in front of it -- only rows inside are stored)
+        half_t* g1 = reinterpret_cast<half_t*>(mp.e[0]) + (grow0 + T3_S2) * 256;   // plane A row 0 as E1 = position u + 24
+        half_t* g2 = reinterpret_cast<half_t*>(mp.e[1]) + (grow0 + T3_S3) * 256;   // plane B row 0 = position u + 16
+        half_t* g3 = reinterpret_cast<half_t*>(mp.e[2]) + grow0 * 256;             // plane A row 0 as E3 = position u
+        const uint8_t* rl = reinterpret_cast<const uint8_t*>(rlist[buf]);
+        // E1's kept rows come back into plane A (conv4 of the previous step is through with its rows 0 .. 3)
+        move_rows<T3_H1, NW * 64>(a_hi, a_lo, h1_hi, h1_lo, threadIdx.x);
+        L1::run(xb, xb, wr, EpiTrunk3{a_hi + T3_H1 * TR_RS, a_lo + T3_H1 * TR_RS}, wf(1), W.bias[1], nt0, nt0);
+        build_desc1(min(wn, w1 - 1));  // unconditional (as are the loads below): the compiler's wait counts stay exact
+        __syncthreads();
+        build_desc2(cur_warm, false);
+        L2::run(a_hi, a_lo, wr, EpiTrunk3{b_hi + T3_H2 * TR_RS, b_lo + T3_H2 * TR_RS}, wf(2), W.bias[2], nt0, nt0, CopyRows3<NW>{rl, g1});
+        // E1's last rows wait in H1 for the next step (conv3 is about to overwrite them)
+        move_rows<T3_H1, NW * 64>(h1_hi, h1_lo, a_hi + T3_M * TR_RS, a_lo + T3_M * TR_RS, threadIdx.x);
+        __syncthreads();
+        build_desc3();
+        build_loads();
+        // E3's kept rows come back into plane A rows 0 .. 15 (conv2 is through with them; conv3 writes rows 16 ..)
+        move_rows<T3_H3, NW * 64>(a_hi, a_lo, h3_hi, h3_lo, threadIdx.x);
+        L3::run(b_hi, b_lo, wr, EpiTrunk3{a_hi + T3_H3 * TR_RS, a_lo + T3_H3 * TR_RS}, wf(3), W.bias[3], nt0, nt04, CopyRows3<NW>{rl + 128, g2});
+        __syncthreads();
+        // E3's and E2's last rows are kept for the next step: E3's in H3 (plane A is E1's next), E2's at the top of plane B itself
+        move_rows<T3_H3, NW * 64>(h3_hi, h3_lo, a_hi + T3_M * TR_RS, a_lo + T3_M * TR_RS, threadIdx.x);
+        move_rows<T3_H2, NW * 64>(b_hi, b_lo, b_hi + T3_M * TR_RS, b_lo + T3_M * TR_RS, threadIdx.x);
+        // a warm-up step's E4 rows are not results (its kept rows were not): they go to the dump
+        const EpiE43 e4{cur_warm ? dump : reinterpret_cast<half_t*>(mp.e4) + grow0 * (2 * C4_CH)};
+        // the four-tile part first (it carries the E3 copy slots), the three-tile part last (behind it the next step's conv1
+        // weights are fetched into the registers it frees)
+        if (wave & 1) {  // a = resident tile 1 alone on position tiles 0 .. 3, the pair on tiles 4 .. 6
+            SConv<C4s, void, 0, 2, 2>::template run<1>(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0, CopyRows3<NW>{rl + 256, g3});
+            SConv<C4, C1, 4, 3>::run(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0);
+        } else {         // the pair on position tiles 0 .. 3, a = resident tile 0 alone on tiles 4 .. 6
+            SConv<C4, void, 0, 2, 2>::run(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0, CopyRows3<NW>{rl + 256, g3});
+            SConv<C4s, C1, 4, 3>::template run<0>(a_hi, a_lo, wr, e4, c1f, W.c1f_bias, nt04, nt0);
+        }
+        build_store(buf ^ 1);
+        buf ^= 1;
+        if (last) break;
+        w = wn;
+        warm = bd.warm;
+    }
+    (void)warm;
+}
+
+size_t trunk3_rowlist_bytes(int64_t n_work) { return (size_t)(2 * n_work + 1) * T3_RL; }
+size_t trunk3_dump_bytes() { return (size_t)TR_OWN * 2 * C4_CH * sizeof(uint16_t); }
+
+void launch_trunk3(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
+                   const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w, const TrunkMaps& maps,
+                   uint16_t* dump, int grid) {
+    if (n_tiles <= 0) return;
+    const int n_work = n_tiles * n_views;
+    const dim3 g(min(n_work, grid));
+    if (k1 == 11) {
+        hipLaunchKernelGGL(rowlist3_kernel<11>, dim3(2 * n_work + 1), dim3(128), 0, st, tiles, n_tiles, n_work, ctx, rinfo, bases, sctx, maps.rowlist);
+        hipLaunchKernelGGL(trunk3_kernel<11>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump));
+    } else {
+        hipLaunchKernelGGL(rowlist3_kernel<13>, dim3(2 * n_work + 1), dim3(128), 0, st, tiles, n_tiles, n_work, ctx, rinfo, bases, sctx, maps.rowlist);
+        hipLaunchKernelGGL(trunk3_kernel<13>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump));
+    }
+}
+
+}  // namespace hm
