@@ -35,7 +35,8 @@ class hm_timing_t(C.Structure):
                 ("pack_launches", C.c_int64), ("empty_launches", C.c_int64),
                 ("trunk_ms", C.c_double * 3), ("edge_ms", C.c_double * 3),
                 ("trunk_launches", C.c_int64 * 3), ("edge_launches", C.c_int64 * 3),
-                ("trunk_positions", C.c_int64 * 3)]
+                ("trunk_positions", C.c_int64 * 3),
+                ("group_bases", C.c_int64), ("group_bytes", C.c_int64)]
 
 
 def build(force: bool = False) -> str:

@@ -59,6 +59,7 @@ struct Options {
     int ctx_mask = 7;
     int threads = 0;
     int level = 6;
+    bool ld_out = false;  // -Z: deflate the output with libdeflate (same records, other compressed bytes; ~2.5x less CPU per block)
     int precision = 1;
     // reads are handed to the engine in slabs of at most this many bases, whatever -b says: -b is the reference's outer
     // batch (mod_options.cpp:13), the slab is the granularity of THIS pipeline (decode | stage | GPU | tag + write overlap
@@ -95,6 +96,8 @@ void usage() {
             "               fixed part -R names; every part k is written to MOD-BAM.shard<k>; `%s merge MOD-BAM n` joins them\n"
             "  -C <int>     number of parts for -Q (default: one per 256 MB of BAM)\n"
             "  -z <0-9>     output compression level (default 6)\n"
+            "  -Z           deflate the output with libdeflate where the system has it (BGZF input is inflated with it anyway): the same\n"
+            "               records in fewer CPU seconds, but not the bytes zlib writes at that level\n"
             "  -S <int>     bases per engine slab (pipeline granularity, default 6291456; results do not depend on it)\n"
             "  -T <0|1>     conv1..conv4 once per site (0) / once per read position (1); default: per context, from the site\n"
             "               density of the head of BAM\n",
@@ -160,6 +163,7 @@ bool parse(int argc, char** argv, Options& o) {
         else if (a == "-b") { if (!need(o.read_batch)) return false; }
         else if (a == "-t") { if (!need(o.threads)) return false; }
         else if (a == "-z") { if (!need(o.level)) return false; }
+        else if (a == "-Z") o.ld_out = true;
         else if (a == "-p") { if (!need(o.precision)) return false; }
         else if (a == "-T") { if (!need(o.trunk)) return false; }
         else if (a == "-S") {
@@ -233,24 +237,35 @@ bool parse_shard(const char* arg, Shard& sh) {
     return sscanf(arg, "%d/%d", &sh.rank, &sh.world) == 2 && sh.world >= 1 && sh.rank >= 0 && sh.rank < sh.world;
 }
 
-std::string shard_path(const std::string& out, const Shard& sh) {
-    return sh.world == 1 ? out : out + ".shard" + std::to_string(sh.rank);
+// (a run that is not sharded writes OUT itself; a queue run always writes OUT.shard<k>, also when the queue has a single part)
+std::string shard_path(const std::string& out, const Shard& sh, bool queued = false) {
+    return sh.world == 1 && !queued ? out : out + ".shard" + std::to_string(sh.rank);
 }
 
 // ---- a work queue over processes ------------------------------------------------------------------------------------------
 // The counter is a small text file; a claim is read-increment-write under an exclusive flock.  Ranks of one node (the
 // reference is a single-node program; so is a one-process-per-GPU job) share the file system, nothing else is needed.
-int claim_chunk(const std::string& path) {
+// Returns the claimed part, or -1 with `err` set when the counter cannot be reached (an unwritable directory, a file system
+// without flock): that is a failure of the run, not an empty queue.
+int claim_chunk(const std::string& path, std::string& err) {
     const int fd = open(path.c_str(), O_RDWR | O_CREAT, 0644);
-    if (fd < 0) return -1;
+    if (fd < 0) {
+        err = "work queue " + path + ": " + strerror(errno);
+        return -1;
+    }
     int k = -1;
     if (flock(fd, LOCK_EX) == 0) {
         char buf[32] = {0};
         const ssize_t n = pread(fd, buf, sizeof buf - 1, 0);
         k = n > 0 ? atoi(buf) : 0;
         const int len = snprintf(buf, sizeof buf, "%d\n", k + 1);
-        if (pwrite(fd, buf, (size_t)len, 0) != len || ftruncate(fd, len) != 0) k = -1;
+        if (n < 0 || pwrite(fd, buf, (size_t)len, 0) != len || ftruncate(fd, len) != 0) {
+            err = "work queue " + path + ": " + strerror(errno);
+            k = -1;
+        }
         flock(fd, LOCK_UN);
+    } else {
+        err = "work queue " + path + ": flock: " + strerror(errno);
     }
     close(fd);
     return k;
@@ -269,6 +284,8 @@ struct ShardSource {
     std::string queue;
     int chunks = 0;
     bool given = false;
+    std::string err;  // set when the queue could not be reached: the caller must fail, not finish
+    bool queued() const { return !queue.empty(); }
     bool next(Shard& sh) {
         if (queue.empty()) {
             if (given) return false;
@@ -276,30 +293,64 @@ struct ShardSource {
             sh = fixed;
             return true;
         }
-        const int k = claim_chunk(queue);
+        const int k = claim_chunk(queue, err);
         if (k < 0 || k >= chunks) return false;
         sh = Shard{k, chunks};
         return true;
     }
 };
 
+// What open_shard learns about a file once per PROCESS: a queue run opens many parts of the same input, and the scan of the BGZF
+// block offsets (one seek and two short reads per block) costs as much as reading the file's index would -- per part it would be
+// (blocks in the file) x (parts per rank) system calls, more than the GPU work of a large input.
+struct ShardIndex {
+    bool valid = false;
+    std::vector<int64_t> offs;  // compressed offset of every BGZF block
+    int64_t fsize = 0, first_rec_block = 0;
+    BamHeader hdr;
+    int scans = 0;  // how often the file's blocks were scanned (bamcopy reports it: tests/test_dist_gloo.py)
+};
+
 // reads the header (every rank needs the reference count), then positions `in` at the shard's first record;
-// end_off = compressed offset at which the next rank's records start
-bool open_shard(BgzfReader& in, const std::string& path, const Shard& sh, BamHeader& hdr, int64_t& end_off, std::string& err) {
-    if (in.block_offset() != 0 && !in.seek_block(0)) { err = in.error(); return false; }  // (a reader that has served another part)
-    hdr = BamHeader();
-    if (!read_header(in, hdr, err)) return false;
+// end_off = compressed offset at which the next rank's records start.  `idx` carries the header and the block offsets from one
+// part to the next (filled by the first call of the process).
+bool open_shard(BgzfReader& in, const std::string& path, const Shard& sh, BamHeader& hdr, int64_t& end_off, std::string& err,
+                ShardIndex* idx = nullptr) {
+    ShardIndex local;
+    ShardIndex& ix = idx ? *idx : local;
     end_off = INT64_MAX;
-    if (sh.world == 1) return true;
-    std::vector<int64_t> offs;
-    int64_t fsize = 0;
-    if (!scan_bgzf_blocks(path, offs, fsize, err)) return false;
-    const int64_t first_rec_block = in.block_offset();
+    bool at_first = false;  // the reader stands right behind the header
+    if (!ix.valid) {
+        at_first = true;
+        if (in.block_offset() != 0 && !in.seek_block(0)) { err = in.error(); return false; }
+        ix.hdr = BamHeader();
+        if (!read_header(in, ix.hdr, err)) return false;
+        ix.first_rec_block = in.block_offset();
+        if (sh.world > 1) {
+            if (!scan_bgzf_blocks(path, ix.offs, ix.fsize, err)) return false;
+            ++ix.scans;
+        }
+        ix.valid = true;
+        hdr = ix.hdr;
+        if (sh.world == 1) return true;
+    } else {
+        hdr = ix.hdr;
+        if (sh.world == 1) {  // (the whole file again)
+            if (!in.seek_block(0)) { err = in.error(); return false; }
+            BamHeader h2;
+            return read_header(in, h2, err);
+        }
+        if (ix.offs.empty()) {
+            if (!scan_bgzf_blocks(path, ix.offs, ix.fsize, err)) return false;
+            ++ix.scans;
+        }
+    }
+    const int64_t first_rec_block = ix.first_rec_block;
     auto bound = [&](int k) -> int64_t {
-        if (k >= sh.world) return fsize;
-        const int64_t target = fsize / sh.world * k;
-        auto it = std::lower_bound(offs.begin(), offs.end(), target);
-        const int64_t b = it == offs.end() ? fsize : *it;
+        if (k >= sh.world) return ix.fsize;
+        const int64_t target = ix.fsize / sh.world * k;
+        auto it = std::lower_bound(ix.offs.begin(), ix.offs.end(), target);
+        const int64_t b = it == ix.offs.end() ? ix.fsize : *it;
         return std::max(b, first_rec_block);  // ranges that would start inside the header collapse onto the first record
     };
     const int64_t start = bound(sh.rank);
@@ -308,7 +359,12 @@ bool open_shard(BgzfReader& in, const std::string& path, const Shard& sh, BamHea
         end_off = -1;
         return true;
     }
-    if (start == first_rec_block) return true;  // begins right behind the header: the reader is already there
+    if (start == first_rec_block) {  // begins right behind the header
+        if (at_first) return true;  // (the reader is already there)
+        if (!in.seek_block(0)) { err = in.error(); return false; }
+        BamHeader h2;
+        return read_header(in, h2, err);
+    }
     if (!in.seek_block(start)) { err = in.error(); return false; }
     if (!find_record_start(in, (int)hdr.refs.size(), err)) {
         if (!err.empty()) return false;
@@ -337,7 +393,12 @@ int head_trunk_mask(const Options& o, std::string& err) {
         recs.push_back(std::move(r));
     }
     if (!err.empty()) return -1;
+    // only the reads the engine will call: it counts densities over accepted reads, and so must this estimate (reads below -l and
+    // reads without the four kinetics arrays are passed through uncalled)
     for (const BamRecord& r : recs) {
+        if (r.l_qseq() < o.min_read_size) continue;
+        const KineticsView kv = kinetics_of(r);
+        if (!kv.arr[0] || !kv.arr[1] || !kv.arr[2] || !kv.arr[3]) continue;
         hm_read_t d{};
         d.l_qseq = r.l_qseq();
         d.seq4 = r.seq4();
@@ -363,6 +424,7 @@ int cmd_call(int argc, char** argv) {
         return o.help ? 0 : EXIT_FAILURE;  // -h / -v exit 0 like the reference (mod_options.cpp:62-71)
     }
     const auto t0 = std::chrono::steady_clock::now();
+    if (o.ld_out) bam_use_libdeflate_compress(true);
     BgzfReader in(o.in, o.threads);
     if (!in.ok()) { fprintf(stderr, "[%s] %s\n", kName, in.error().c_str()); return EXIT_FAILURE; }
     std::string err;
@@ -378,9 +440,8 @@ int cmd_call(int argc, char** argv) {
         hm_set_option(eng[d], "min_read_size", o.min_read_size);
         hm_set_option(eng[d], "precision", o.precision);
         hm_set_option(eng[d], "slots", 3);
-        // trunk groups of 2 Mi bases: the engine's default (16 Mi) is for long runs of large slabs -- its maps are 64 GB, and
-        // allocating them costs this command ~0.2 s per 16 GB; with 6 Mi slabs 2 Mi groups measured fastest end to end
-        hm_set_option(eng[d], "group_bases", int64_t(2) << 20);
+        // (trunk read groups: the engine's own default -- sized from free device memory, the same as bench.py runs; a group never
+        //  exceeds the slab it is cut from, and the maps are allocated for the largest group actually seen)
     }
     {
         int tmask = o.trunk == 0 ? 0 : o.trunk == 1 ? o.ctx_mask : head_trunk_mask(o, err);
@@ -429,7 +490,7 @@ int cmd_call(int argc, char** argv) {
     auto finish = [&](Job& jb) {
         if (jb.open_part) {  // the first job of a part: its output file (and, for the first part of the input, the header)
             close_out();
-            out_path = shard_path(o.out, jb.part);
+            out_path = shard_path(o.out, jb.part, !o.queue.empty());
             out.reset(new BgzfWriter(out_path, o.threads, o.level));
             if (!out->ok()) { fprintf(stderr, "[%s] %s\n", kName, out->error().c_str()); failed = true; return; }
             if (jb.part.rank == 0) write_header(*out, jb.hdr);
@@ -522,9 +583,10 @@ int cmd_call(int argc, char** argv) {
     };
 
     Shard part;
+    ShardIndex sidx;
     while (!failed && src.next(part)) {
         BamHeader hdr;
-        if (!open_shard(in, o.in, part, hdr, end_off, err)) { fprintf(stderr, "[%s] %s: %s\n", kName, o.in.c_str(), err.c_str()); failed = true; break; }
+        if (!open_shard(in, o.in, part, hdr, end_off, err, &sidx)) { fprintf(stderr, "[%s] %s: %s\n", kName, o.in.c_str(), err.c_str()); failed = true; break; }
         {
             Job op;
             op.part = part;
@@ -576,6 +638,10 @@ int cmd_call(int argc, char** argv) {
             cur ^= 1;
         }
     }
+    if (!src.err.empty()) {  // the queue could not be reached: not the same as "no part left"
+        fprintf(stderr, "[%s] %s\n", kName, src.err.c_str());
+        failed = true;
+    }
     {
         std::lock_guard<std::mutex> lk(mu);
         no_more = true;
@@ -612,13 +678,14 @@ int cmd_bamcopy(int argc, char** argv) {
     BgzfReader in(argv[a], 4);
     if (!in.ok()) { fprintf(stderr, "%s\n", in.error().c_str()); return EXIT_FAILURE; }
     Shard sh;
+    ShardIndex sidx;
     size_t parts = 0, n = 0;
     while (src.next(sh)) {
         BamHeader h;
         std::string err;
         int64_t end_off = 0;
-        if (!open_shard(in, argv[a], sh, h, end_off, err)) { fprintf(stderr, "%s%s\n", in.error().c_str(), err.c_str()); return EXIT_FAILURE; }
-        BgzfWriter out(shard_path(argv[a + 1], sh), 4, 6);
+        if (!open_shard(in, argv[a], sh, h, end_off, err, &sidx)) { fprintf(stderr, "%s%s\n", in.error().c_str(), err.c_str()); return EXIT_FAILURE; }
+        BgzfWriter out(shard_path(argv[a + 1], sh, src.queued()), 4, 6);
         if (!out.ok()) return EXIT_FAILURE;
         if (sh.rank == 0) write_header(out, h);
         BamRecord r;
@@ -630,8 +697,9 @@ int cmd_bamcopy(int argc, char** argv) {
         if (!out.close()) return EXIT_FAILURE;
         ++parts;
     }
+    if (!src.err.empty()) { fprintf(stderr, "[%s] %s\n", kName, src.err.c_str()); return EXIT_FAILURE; }
     if (src.queue.empty()) fprintf(stderr, "[%s] bamcopy: rank %d/%d wrote %zu records\n", kName, sh.rank, sh.world, n);
-    else fprintf(stderr, "[%s] bamcopy: took %zu of %d parts from the queue, wrote %zu records\n", kName, parts, src.chunks, n);
+    else fprintf(stderr, "[%s] bamcopy: took %zu of %d parts from the queue, wrote %zu records, block scans %d\n", kName, parts, src.chunks, n, sidx.scans);
     return 0;
 }
 

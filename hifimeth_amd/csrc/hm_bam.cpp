@@ -1,6 +1,7 @@
 // hm_bam.cpp -- see hm_bam.h
 #include "hm_bam.h"
 
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -9,6 +10,89 @@
 #include <cstring>
 #include <thread>
 #include <unordered_set>
+
+// ---- libdeflate, when the image has it (dlopen of libdeflate.so.0: no build-time dependency) ----------------------------------------
+// BGZF blocks are small independent raw-deflate streams: libdeflate inflates them ~2-3x faster than zlib and checks CRC-32 ~5x faster
+// (the reference's reader is htslib, which uses libdeflate the same way when built with it; sam_batch.hpp:12-23).  Inflate and CRC
+// give the same bytes whichever library runs; DEFLATE output differs between the two, so the writer keeps zlib unless asked
+// (hm_bam_use_libdeflate_compress), and output files stay byte-identical to earlier rounds' at the same -z.
+namespace {
+struct LibDeflate {
+    void* h = nullptr;
+    void* (*alloc_d)() = nullptr;
+    int (*inflate)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*free_d)(void*) = nullptr;
+    void* (*alloc_c)(int) = nullptr;
+    size_t (*deflate)(void*, const void*, size_t, void*, size_t) = nullptr;
+    size_t (*bound)(void*, size_t) = nullptr;
+    void (*free_c)(void*) = nullptr;
+    uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
+    LibDeflate() {
+        if (getenv("HM_NO_LIBDEFLATE")) return;
+        for (const char* n : {"libdeflate.so.0", "libdeflate.so"}) {
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) return;
+        alloc_d = (void* (*)())dlsym(h, "libdeflate_alloc_decompressor");
+        inflate = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_deflate_decompress");
+        free_d = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
+        alloc_c = (void* (*)(int))dlsym(h, "libdeflate_alloc_compressor");
+        deflate = (size_t (*)(void*, const void*, size_t, void*, size_t))dlsym(h, "libdeflate_deflate_compress");
+        bound = (size_t (*)(void*, size_t))dlsym(h, "libdeflate_deflate_compress_bound");
+        free_c = (void (*)(void*))dlsym(h, "libdeflate_free_compressor");
+        crc = (uint32_t (*)(uint32_t, const void*, size_t))dlsym(h, "libdeflate_crc32");
+        if (!alloc_d || !inflate || !free_d || !alloc_c || !deflate || !bound || !free_c || !crc) h = nullptr;
+    }
+    bool ok() const { return h != nullptr; }
+};
+const LibDeflate& libdeflate() {
+    static const LibDeflate ld;
+    return ld;
+}
+// one decompressor / compressor per thread (they are not thread-safe, and allocating one per 64 KB block costs more than the block)
+struct TlsD {
+    void* d = nullptr;
+    ~TlsD() { if (d) libdeflate().free_d(d); }
+};
+struct TlsC {
+    void* c = nullptr;
+    int level = -1;
+    ~TlsC() { if (c) libdeflate().free_c(c); }
+};
+std::atomic<bool> g_ld_compress{false};
+uint32_t crc_of(const uint8_t* p, size_t n) {
+    const LibDeflate& ld = libdeflate();
+    return ld.ok() ? ld.crc(0, p, n) : (uint32_t)crc32(0L, p, (uInt)n);
+}
+// raw-deflate stream -> exactly `isize` bytes; false on any error
+bool inflate_block(const uint8_t* in, size_t n_in, uint8_t* out, size_t isize) {
+    const LibDeflate& ld = libdeflate();
+    if (ld.ok()) {
+        thread_local TlsD t;
+        if (!t.d) t.d = ld.alloc_d();
+        if (t.d) {
+            size_t got = 0;
+            return ld.inflate(t.d, in, n_in, out, isize, &got) == 0 && got == isize;
+        }
+    }
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<uint8_t*>(in);
+    zs.avail_in = (uInt)n_in;
+    zs.next_out = out;
+    zs.avail_out = (uInt)isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && zs.total_out == isize;
+}
+}  // namespace
+
+namespace hmbam {
+bool bam_have_libdeflate() { return libdeflate().ok(); }
+void bam_use_libdeflate_compress(bool on) { g_ld_compress = on && libdeflate().ok(); }
+}  // namespace hmbam
 
 namespace hmbam {
 
@@ -146,19 +230,7 @@ void BgzfReader::load(Chunk& c, int64_t from) {
     parallel_for((int)blocks.size(), threads_, [&](int i) {
         Blk& b = blocks[(size_t)i];
         if (b.isize == 0) return;
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, -15) != Z_OK) {
-            bad = true;
-            return;
-        }
-        zs.next_in = b.comp.data();
-        zs.avail_in = (uInt)b.comp.size();
-        zs.next_out = c.data.data() + b.at;
-        zs.avail_out = (uInt)b.isize;
-        const int rc = inflate(&zs, Z_FINISH);
-        inflateEnd(&zs);
-        if (rc != Z_STREAM_END || zs.total_out != b.isize || crc32(0L, c.data.data() + b.at, (uInt)b.isize) != b.crc) bad = true;
+        if (!inflate_block(b.comp.data(), b.comp.size(), c.data.data() + b.at, b.isize) || crc_of(c.data.data() + b.at, b.isize) != b.crc) bad = true;
     });
     if (bad) {
         c.err = "BGZF block failed to inflate (corrupt data or CRC mismatch)";
@@ -384,28 +456,43 @@ void BgzfWriter::flush_blocks(bool all) {
         const size_t off = (size_t)i * BGZF_MAX_PAYLOAD;
         const size_t len = std::min(BGZF_MAX_PAYLOAD, buf_.size() - off);
         std::vector<uint8_t>& o = out[(size_t)i];
-        o.resize(18 + compressBound((uLong)len) + 8);
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
-            bad = true;
-            return;
-        }
-        zs.next_in = const_cast<uint8_t*>(buf_.data() + off);
-        zs.avail_in = (uInt)len;
-        zs.next_out = o.data() + 18;
-        zs.avail_out = (uInt)(o.size() - 18 - 8);
-        const int rc = deflate(&zs, Z_FINISH);
-        const size_t clen = zs.total_out;
-        deflateEnd(&zs);
-        if (rc != Z_STREAM_END || 18 + clen + 8 > 0x10000) {
-            bad = true;
-            return;
+        size_t clen = 0;
+        if (g_ld_compress) {
+            const LibDeflate& ld = libdeflate();
+            thread_local TlsC t;
+            if (!t.c || t.level != level_) {
+                if (t.c) ld.free_c(t.c);
+                t.c = ld.alloc_c(level_ < 1 ? 1 : level_);  // (libdeflate's level 0 stores; zlib's level 0 is not used by the CLI either)
+                t.level = level_;
+            }
+            if (!t.c) { bad = true; return; }
+            o.resize(18 + ld.bound(t.c, len) + 8);
+            clen = ld.deflate(t.c, buf_.data() + off, len, o.data() + 18, o.size() - 18 - 8);
+            if (clen == 0 || 18 + clen + 8 > 0x10000) { bad = true; return; }
+        } else {
+            o.resize(18 + compressBound((uLong)len) + 8);
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (deflateInit2(&zs, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+                bad = true;
+                return;
+            }
+            zs.next_in = const_cast<uint8_t*>(buf_.data() + off);
+            zs.avail_in = (uInt)len;
+            zs.next_out = o.data() + 18;
+            zs.avail_out = (uInt)(o.size() - 18 - 8);
+            const int rc = deflate(&zs, Z_FINISH);
+            clen = zs.total_out;
+            deflateEnd(&zs);
+            if (rc != Z_STREAM_END || 18 + clen + 8 > 0x10000) {
+                bad = true;
+                return;
+            }
         }
         static const uint8_t head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43, 0x02, 0x00};
         memcpy(o.data(), head, 16);
         wr16(o.data() + 16, (uint32_t)(18 + clen + 8 - 1));
-        wr32(o.data() + 18 + clen, (uint32_t)crc32(0L, buf_.data() + off, (uInt)len));
+        wr32(o.data() + 18 + clen, crc_of(buf_.data() + off, len));
         wr32(o.data() + 18 + clen + 4, (uint32_t)len);
         o.resize(18 + clen + 8);
     });

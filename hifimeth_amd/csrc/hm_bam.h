@@ -117,6 +117,10 @@ struct AuxField {
 bool next_aux(const uint8_t*& p, const uint8_t* end, AuxField& f);
 
 bool read_header(BgzfReader& in, BamHeader& h, std::string& err);
+// libdeflate (dlopen'ed when the system has it) inflates and checksums BGZF blocks; the writer deflates with zlib unless asked otherwise
+// (the compressed bytes differ between the two libraries, the records do not)
+bool bam_have_libdeflate();
+void bam_use_libdeflate_compress(bool on);
 void write_header(BgzfWriter& out, const BamHeader& h);
 bool read_record(BgzfReader& in, BamRecord& r, std::string& err);
 void write_record(BgzfWriter& out, const BamRecord& r);

@@ -172,7 +172,11 @@ struct hm_engine {
     int trunk_mask_auto = -1;  // contexts that take the dense trunk under trunk = 2 (-1: not decided yet); guarded by mu
     // reads per trunk group: their maps take ~3.9 KB per base (16 Mi bases: 64 GB of the 288).  Larger groups = fewer launches of the
     // resident-weight kernels, which load their weights once per launch: streamed bench 56.5 M sites/s at 2 Mi, 57.7 M at 16 Mi, 56.4 M at 32 Mi
-    int64_t group_bases = int64_t(16) << 20;
+    // 0 (default) = sized from the device's FREE memory when the first read is staged: the group buffers (maps, edge rows, row lists)
+    // take at most a quarter of it, and at most 16 Mi bases (effective_group_bases).  Two engines on one device, or ranks sharing a
+    // GPU, then fit by construction; hm_get_timing reports what was chosen and what is allocated.
+    int64_t group_bases = 0;
+    int64_t group_bases_eff = 0;
     bool stamps_on = false;
     std::vector<unsigned long long> stamp_sum;
     bool timing = false;
@@ -197,6 +201,24 @@ struct hm_engine {
 };
 
 namespace {
+
+// Device bytes per base of a read group: E1..E3 maps (2 views x 512 B each), E4 (2 x 384 B), the sites' edge rows (768 B) and map-row
+// numbers, row lists -- times the 25 % head-room DevBuf::reserve adds.
+constexpr int64_t GROUP_BYTES_PER_BASE = (3 * 2 * 512 + 2 * 384 + 768 + 4 + 8) * 5 / 4;
+
+int64_t effective_group_bases(hm_engine* e) {
+    if (e->group_bases > 0) return e->group_bases;
+    if (e->group_bases_eff > 0) return e->group_bases_eff;
+    size_t free_b = 0, total_b = 0;
+    int64_t gb = int64_t(2) << 20;
+    if (hipSetDevice(e->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+        gb = (int64_t)(free_b / 4) / GROUP_BYTES_PER_BASE;
+        gb = std::min<int64_t>(gb, int64_t(16) << 20);
+        gb = std::max<int64_t>(gb >> 20 << 20, int64_t(1) << 20);  // whole Mi, at least one
+    }
+    e->group_bases_eff = gb;
+    return gb;
+}
 
 int fail(hm_engine* e, int code, const std::string& msg) {
     if (e) {
@@ -462,7 +484,7 @@ int stage_read(hm_batch* b, int32_t read_id, int32_t l_qseq, int32_t flag, const
         const int ridx = (int)b->reads.n;
         // dense trunk: the read's maps cover view positions [-200, L + 200) in tiles of TR_OWN; a new group starts when
         // the current one holds group_bases
-        if (b->groups.empty() || b->groups.back().bases >= e->group_bases)
+        if (b->groups.empty() || b->groups.back().bases >= effective_group_bases(e))
             b->groups.push_back(hm_batch::Group{(int)b->chunks.n, (int)b->chunks.n, (int)b->tiles.n, (int)b->tiles.n, 0, 0});
         hm_batch::Group& g = b->groups.back();
         const int ntile = (l_qseq + 2 * TR_PAD + TR_OWN - 1) / TR_OWN;
@@ -892,7 +914,7 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
         if (value < 16) return fail(e, HM_EINVAL, "tail_slice must be at least 16");
         e->tail_slice = value;
     } else if (k == "group_bases") {
-        if (value < 1) return fail(e, HM_EINVAL, "group_bases must be positive");
+        if (value < 0) return fail(e, HM_EINVAL, "group_bases must be positive (0: sized from free device memory)");
         e->group_bases = value;
     } else if (k == "slots") {
         if (value < 1 || value > 16) return fail(e, HM_EINVAL, "slots must be 1..16");
@@ -1103,7 +1125,7 @@ int64_t hm_batch_submit_reads(hm_batch_t* b, const hm_read_t* reads, int64_t n, 
             rd.read_id = r.read_id;
             for (int k = 0; k < 4; ++k) rd.w[k] = r.width[k];
             const int ridx = (int)b->reads.n;
-            if (b->groups.empty() || b->groups.back().bases >= e->group_bases)
+            if (b->groups.empty() || b->groups.back().bases >= effective_group_bases(e))
                 b->groups.push_back(hm_batch::Group{(int)b->chunks.n, (int)b->chunks.n, (int)b->tiles.n, (int)b->tiles.n, 0, 0});
             hm_batch::Group& g = b->groups.back();
             const int ntile = (r.l_qseq + 2 * TR_PAD + TR_OWN - 1) / TR_OWN;
@@ -1351,6 +1373,10 @@ int hm_get_timing(hm_engine_t* e, hm_timing_t* t) {
     if (!e || !t) return HM_EINVAL;
     std::lock_guard<std::mutex> lk(e->mu);
     *t = e->acc;
+    t->group_bases = e->group_bases > 0 ? e->group_bases : e->group_bases_eff;
+    t->group_bytes = 0;
+    for (const DevBuf* d : {&e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4, &e->d_rowlist, &e->d_edge4, &e->d_e4row, &e->d_x6, &e->d_dump})
+        t->group_bytes += (int64_t)d->cap;
     return HM_OK;
 }
 

@@ -77,6 +77,8 @@ typedef struct {
     double trunk_ms[3], edge_ms[3]; /* dense trunk (conv1..conv4 over whole reads) and window-edge kernels */
     int64_t trunk_launches[3], edge_launches[3];
     int64_t trunk_positions[3]; /* (read, strand view) positions evaluated by the timed trunk launches */
+    int64_t group_bases;        /* bases per trunk read group in force (option "group_bases", or what the engine sized from free memory) */
+    int64_t group_bytes;        /* device bytes the engine holds for a read group's maps, edge rows and hand-off buffers */
 } hm_timing_t;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
@@ -93,10 +95,10 @@ const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a fa
  * profiles/r02_term_error_table.txt), and the part that holds it is 1 % of the FLOPs), "trunk" (2 = per context by the site density of the FIRST batch the engine is given -- counted
  * on the host when that batch is queued and then fixed for the engine's lifetime, so the calls never depend on host timing --
  * default; 1 = conv1..conv4 once per read position; 0 = once per site; every precision has both forms), "trunk_mask" (0..7: that
- * choice made by the caller, see hm_trunk_mask_for_reads), "trunk_impl" (1 = streaming 4-wave trunk kernel,
- * default; 2 = the same on 8 waves; 0 = the 8-wave ConvH form; byte-identical results), "edge_impl" (1 = edge2_kernel, default; 0 = round 2's
- * edge_kernel; byte-identical), "tail_impl" (1 = tail with register-resident weights, default; 0 = the streaming tail; byte-identical),
- * "group_bases" (reads per trunk group, default 16 Mi bases: their maps take 3.9 KB of HBM per base), "num_cu" (workgroups of the persistent kernels), "stamps" (diagnostic) */
+ * choice made by the caller, see hm_trunk_mask_for_reads), "trunk_impl" (3 = the streaming trunk as a sliding window over
+ * consecutive tiles, default; 1 = streaming 4-wave trunk kernel; 2 = the same on 8 waves; 0 = the 8-wave ConvH form; byte-identical results), "edge_impl" (1 = edge2_kernel, default; 0 = round 2's
+ * edge_kernel; byte-identical), "tail_impl" (1 = tail with register-resident weights, default; 2 = the split tail: conv5 + conv6, then conv7 .. softmax over 16 sites per pass ("tail_slice": sites per launch pair); 0 = the streaming tail; byte-identical),
+ * "group_bases" (reads per trunk group; default 0 = sized when the first read is staged so that a group's buffers, 5.8 KB per base, take at most a quarter of the device's free memory, and at most 16 Mi bases), "num_cu" (workgroups of the persistent kernels), "stamps" (diagnostic) */
 int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
 
 /* ---- staging: the EvalKmerFeaturesGenerator::init seam ----------------------------------- */

@@ -260,3 +260,46 @@ def test_queue_parts_are_claimed_exactly_once(tmp_path):
     assert int(open(qf).read()) == n + 3                    # every process made one claim past the end
     subprocess.check_call([cli, "merge", out, str(n)])
     assert _payload(out) == _payload(one)
+
+
+def test_queue_failures_are_errors_and_a_single_part_keeps_its_shard_name(tmp_path):
+    """a rank that cannot reach the counter file (here: a directory that does not exist) must fail, not exit 0 having
+    done nothing; and a queue run writes OUT.shard<k> even when the queue has one part (`merge OUT 1` then finds it)."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bamutil
+    from hifimeth_amd.synth import synth_reads
+    cli = os.path.join(ROOT, "hifimeth_amd", "bin", "hifimeth-hip")
+    reads = synth_reads(12, seed=31, median_len=3000, sigma=0.3)
+    src, one, out = str(tmp_path / "in.bam"), str(tmp_path / "one.bam"), str(tmp_path / "q.bam")
+    bamutil.reads_to_bam(src, reads, level=1)
+    subprocess.check_call([cli, "bamcopy", src, one], stderr=subprocess.DEVNULL)
+    p = subprocess.run([cli, "bamcopy", "-Q", str(tmp_path / "no_such_dir" / "counter"), "-C", "4", src, out], stderr=subprocess.PIPE, text=True)
+    assert p.returncode != 0 and "work queue" in p.stderr, p.stderr
+    subprocess.check_call([cli, "bamcopy", "-Q", str(tmp_path / "counter1"), "-C", "1", src, out], stderr=subprocess.DEVNULL)
+    assert os.path.exists(out + ".shard0") and not os.path.exists(out)
+    subprocess.check_call([cli, "merge", out, "1"])
+    assert _payload(out) == _payload(one)
+
+
+def test_many_queue_parts_per_process_scan_the_input_once(tmp_path):
+    """a process that takes many parts of one input must not re-scan the file's BGZF blocks per part (one seek and
+    two reads per block, times the parts: more than the GPU work of a large input).  One process takes all 40 parts: the output is the
+    input and the blocks were scanned once."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bamutil
+    from hifimeth_amd.synth import synth_reads
+    cli = os.path.join(ROOT, "hifimeth_amd", "bin", "hifimeth-hip")
+    reads = synth_reads(300, seed=33, median_len=5000, sigma=0.4)
+    src, one, out, qf = str(tmp_path / "in.bam"), str(tmp_path / "one.bam"), str(tmp_path / "q.bam"), str(tmp_path / "counter")
+    bamutil.reads_to_bam(src, reads, level=1)
+    subprocess.check_call([cli, "bamcopy", src, one], stderr=subprocess.DEVNULL)
+    n = 40
+    p = subprocess.run([cli, "bamcopy", "-Q", qf, "-C", str(n), src, out], stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "took 40 of 40 parts" in p.stderr and "block scans 1" in p.stderr, p.stderr
+    subprocess.check_call([cli, "merge", out, str(n)])
+    assert _payload(out) == _payload(one)

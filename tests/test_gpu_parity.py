@@ -461,8 +461,8 @@ def test_path_follows_site_density_of_the_first_batch(oracle, oracle_models):
 
 
 def test_trunk_groups_do_not_change_the_calls(oracle, oracle_models):
-    """The dense trunk cuts a batch into read groups that reuse one set of map buffers (engine option group_bases, default
-    2 Mi bases; bench.py's steps run ~38 groups per context).  With group_bases = 32 Ki the same reads fall into many groups
+    """The dense trunk cuts a batch into read groups that reuse one set of map buffers (engine option group_bases; default: sized
+    from free device memory, at most 16 Mi bases -- bench.py's 182-Mbase steps run ~15 groups per context).  With group_bases = 32 Ki the same reads fall into many groups
     -- a read that ends a group, a read that starts one, a 70 kb read that is a group of its own, a crowd of minimum-length
     reads -- and the calls must be byte-identical to the one-group run and within 1e-4 of the oracle: results may not
     depend on the batch cut (mod_main.cpp:330-362), in the split-half and in the strict-fp32 arithmetic."""
@@ -553,13 +553,41 @@ def test_streaming_trunk_is_byte_identical_to_the_8_wave_form():
     from hifimeth_amd import MethylationCaller
     reads = _mixed_reads() + synth_reads(6, seed=77, median_len=5000, sigma=0.5, frac_wide=0.3)
     out = []
-    for impl in (0, 1, 2):  # 8-wave ConvH form, streaming on 4 waves (default), streaming on 8 waves
+    for impl in (0, 1, 2, 3):  # 8-wave ConvH form, streaming on 4 waves, streaming on 8 waves, sliding window (default)
         with MethylationCaller(device=0) as m:
             m.set_option("trunk", 1)
             m.set_option("trunk_impl", impl)
             out.append(m.call(reads).copy())
-    assert len(out[0]) == len(out[1]) == len(out[2]) > 1000
-    assert out[0].tobytes() == out[1].tobytes() == out[2].tobytes()
+    assert len(out[0]) == len(out[1]) == len(out[2]) == len(out[3]) > 1000
+    assert out[0].tobytes() == out[1].tobytes() == out[2].tobytes() == out[3].tobytes()
+
+
+@pytest.mark.gpu
+def test_sliding_window_trunk_is_byte_identical_whatever_the_runs_of_tiles():
+    """trunk_impl = 3 (hm_trunk3.hip): a workgroup walks a contiguous run of tiles and keeps every layer's right-hand rows for the next
+    tile; kept rows are rebuilt by a warm-up step at the start of a run and of a read.  Where the runs are cut depends on the number
+    of workgroups (num_cu) and on the read groups: 1, 3, 7, 256 workgroups and many small groups -- runs that start in the middle of
+    a read, runs of a single tile, reads of a single tile, more workgroups than tiles -- all give the streaming trunk's calls byte for
+    byte, second batches through the same engine included."""
+    from hifimeth_amd import MethylationCaller
+    reads = _mixed_reads() + synth_reads(9, seed=91, median_len=4000, sigma=0.7, frac_wide=0.3)
+    with MethylationCaller(device=0) as m:
+        m.set_option("trunk", 1)
+        m.set_option("trunk_impl", 1)
+        ref = m.call(reads).copy()
+    assert len(ref) > 1000
+    for num_cu, group_bases in ((1, 0), (3, 0), (7, 32768), (256, 0), (1024, 4096)):
+        with MethylationCaller(device=0) as m:
+            m.set_option("trunk", 1)
+            m.set_option("trunk_impl", 3)
+            m.set_option("num_cu", num_cu)
+            if group_bases:
+                m.set_option("group_bases", group_bases)
+            a = m.call(reads).copy()
+            b = m.call(reads[::-1]).copy()     # other reads first: stale kept rows / maps of the previous batch must not leak
+            c = m.call(reads).copy()
+        assert a.tobytes() == ref.tobytes() == c.tobytes(), (num_cu, group_bases)
+        assert len(b) == len(ref)
 
 
 def test_edge2_is_byte_identical_to_the_staging_edge_kernel():
@@ -596,7 +624,7 @@ def test_resident_tail_is_byte_identical_to_the_streaming_tail():
     cases = [("cpg,chg,chh", reads, None), ("cpg,chg,chh", reads[:1], None), ("cpg", reads[:3], None), ("chh", reads, 32768)]
     for spec, rs, group_bases in cases:
         out = []
-        for impl in (0, 1):
+        for impl in (0, 1, 2):   # 2 = the split tail (hm_tail_s.hip: conv5 + conv6 | conv7 .. softmax over 16 sites per pass)
             with MethylationCaller(contexts=spec, device=0, timing=True) as m:
                 m.set_option("trunk", 1)
                 m.set_option("tail_impl", impl)
@@ -604,5 +632,36 @@ def test_resident_tail_is_byte_identical_to_the_streaming_tail():
                     m.set_option("group_bases", group_bases)
                 out.append(m.call(rs).copy())
                 out.append(m.call(rs).copy())      # a second batch through the same engine (buffers reused)
-        assert len(out[0]) == len(out[2]) > 50, (spec, len(out[0]))
-        assert out[0].tobytes() == out[1].tobytes() == out[2].tobytes() == out[3].tobytes(), spec
+        assert len(out[0]) == len(out[2]) == len(out[4]) > 50, (spec, len(out[0]))
+        assert out[0].tobytes() == out[1].tobytes() == out[2].tobytes() == out[3].tobytes() == out[4].tobytes() == out[5].tobytes(), spec
+    # the split tail in launches of 64 sites (engine option tail_slice): many launch pairs per context, the hand-off buffer reused
+    with MethylationCaller(device=0) as m:
+        m.set_option("trunk", 1)
+        m.set_option("tail_impl", 0)
+        ref = m.call(reads).copy()
+    with MethylationCaller(device=0) as m:
+        m.set_option("trunk", 1)
+        m.set_option("tail_impl", 2)
+        m.set_option("tail_slice", 64)
+        got = m.call(reads).copy()
+    assert got.tobytes() == ref.tobytes()
+
+
+@pytest.mark.gpu
+def test_two_engines_on_one_device_fit_at_the_default_group_size():
+    """VERDICT r03 #6 / ADVICE r03: the default group size is taken from the device's FREE memory (a quarter of it at most for a group's
+    maps, edge rows and row lists, at most 16 Mi bases), so two engines on one device -- or ranks sharing a GPU -- cannot run it out of
+    memory; hm_get_timing reports the size in force and the bytes held."""
+    import torch
+    from hifimeth_amd import MethylationCaller
+    reads = synth_reads(12, seed=93, median_len=5000, sigma=0.4)
+    free0, total = torch.cuda.mem_get_info(0)
+    with MethylationCaller(device=0, timing=True) as a, MethylationCaller(device=0, timing=True) as b:
+        ca = a.call(reads).copy()
+        cb = b.call(reads).copy()
+        ta, tb = a.timing(), b.timing()
+    assert ca.tobytes() == cb.tobytes() and len(ca) > 1000
+    for t in (ta, tb):
+        assert (1 << 20) <= t["group_bases"] <= (16 << 20) and t["group_bases"] % (1 << 20) == 0, t["group_bases"]
+        assert 0 < t["group_bytes"] <= free0 // 4 + (64 << 20), (t["group_bytes"], free0)
+        assert t["group_bases"] * 5800 <= free0 // 4 + (1 << 30), (t["group_bases"], free0)
