@@ -14,7 +14,7 @@ only the synthesis of the reads (the stand-in for BAM decode) happens before it.
 slabs (reads are independent: no data-path collective, weak scaling); `value` is the whole-job sites/s = sum of sites
 over ranks / max time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--no-extras] [--no-e2e] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--workload arabidopsis|human_slice] [--no-extras] [--no-e2e] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -104,7 +104,7 @@ def cpu_baseline(sample, gpu_calls=None, budget_s=25.0, tol=1e-4, what=""):
     return out, parity
 
 
-GROUP_BASES = 16 << 20   # engine default `group_bases`: reads per trunk group (hm_engine.cpp, stage_read); --opt group_bases=N follows
+GROUP_BASES = 16 << 20   # bases per trunk read group: read back from the engine in main() (its default is sized from free device memory)
 
 
 def trunk_groups(reads):
@@ -140,29 +140,31 @@ def parity_sample(reads, per_group=32):
 
 
 def quoted_traffic(tm, launches, sites):
-    """roofline.traffic for the trunk kernel.  HBM bytes come from PMC counters, which need rocprofv3 passes of their own
-    (one counter group per run) and cannot be read from inside this process: the figure is QUOTED from the kept pass of
-    this round (profiles/r03_traffic.json, written by tools/pmc_derive.py from a run of this same command: HBM-side bytes per
-    view position of trunk2_kernel, gfx950 corrections applied) and scaled to this run's positions per launch."""
+    """HBM traffic of the trunk kernel.  HBM bytes come from PMC counters, which need rocprofv3 passes of their own (one counter
+    group per run) and cannot be read from inside this process: `traffic` (measured in THIS run) is therefore null, and the figure
+    of the round's kept full-size pass (profiles/r04_traffic.json, written by tools/pmc_derive.py from tools/prof_r04.sh traffic:
+    this same command, gfx950 corrections applied) is given under `traffic_quoted`, with its source."""
     alg = 28.0 * sites / max(1, launches)   # SURVEY.md 8(d): ~16 B of raw input + 12 B of result per site
     out = {"traffic": None, "algorithmic_bytes": alg,
-           "traffic_note": "HBM bytes need separate rocprofv3 --pmc passes; profiles/r03_traffic.json absent"}
-    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
+           "traffic_note": "HBM bytes need separate rocprofv3 --pmc passes (tools/prof_r04.sh traffic); see traffic_quoted"}
+    path = os.path.join(ROOT, "profiles", "r04_traffic.json")
     try:
-        q = json.load(open(path))["trunk2_kernel"]
-        per_pos = {0: q["k11"], 1: q["k11"], 2: q["k13"]}
+        q = json.load(open(path))
+        k = q["trunk_kernel"]
+        per_pos = {0: k["k11"], 1: k["k11"], 2: k["k13"]}
         tot = sum(tm["trunk_positions"][c] * (per_pos[c]["read_B_per_position"] + per_pos[c]["write_B_per_position"]) for c in range(3))
-        out.update({"traffic": tot / max(1, launches), "traffic_over_algorithmic": tot / max(1, launches) / alg,
-                    "traffic_note": "QUOTED: HBM-side bytes per launch = this run's view positions per launch x the bytes per "
-                                    "position measured by rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections) "
-                                    "on this command; the maps E1..E4 the design parks in HBM are what exceeds the algorithmic bytes",
-                    "quoted": "profiles/r03_traffic.json"})
+        out["traffic_quoted"] = {"bytes_per_launch": tot / max(1, launches), "over_algorithmic": tot / max(1, launches) / alg,
+                                 "source": "profiles/r04_traffic.json", "kernel": q.get("kernel"), "command": q.get("command"),
+                                 "commit": q.get("commit"),
+                                 "note": "HBM-side bytes per view position measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the "
+                                         "full-size bench command (gfx950: FETCH_SIZE doubled), times this run's positions per launch; the "
+                                         "maps E1..E4 the design parks in HBM are what exceeds the algorithmic bytes"}
     except (OSError, KeyError, ValueError):
         pass
     return out
 
 
-def end_to_end(slabs, n_reads, ctx="cpg,chg,chh"):
+def end_to_end(slabs, n_reads, ctx="cpg,chg,chh", extra_flags=()):
     """`hifimeth-hip call IN.bam OUT.bam` with the reference's default flags (mod_options.cpp:10-17) on a synthetic BAM of
     n_reads reads: BGZF inflate -> parse -> stage -> GPU -> MM/ML tags -> deflate, engine start-up included -- the quantity
     the reference's one published figure is about (README.md:31: wall-clock of the whole command)."""
@@ -173,7 +175,8 @@ def end_to_end(slabs, n_reads, ctx="cpg,chg,chh"):
     cli = os.path.join(ROOT, "hifimeth_amd", "bin", "hifimeth-hip")
     if not os.path.exists(cli):
         return {"error": "hifimeth_amd/bin/hifimeth-hip is not built"}
-    reads = [r for s in slabs for r in s][:n_reads]
+    pool = [r for s in slabs for r in s]
+    reads = [pool[i % len(pool)] for i in range(n_reads)]   # (the pool cycles: a 5 GB file needs more reads than six slabs hold)
     tmp = tempfile.mkdtemp(prefix="hm_e2e_")
     try:
         src, dst = os.path.join(tmp, "in.bam"), os.path.join(tmp, "out.bam")
@@ -185,6 +188,12 @@ def end_to_end(slabs, n_reads, ctx="cpg,chg,chh"):
         wall = time.perf_counter() - t0
         if p.returncode != 0:
             return {"error": f"exit {p.returncode}: {p.stderr[-300:]}"}
+        more = {}
+        for fl in extra_flags:   # the same file again with one more flag (e.g. -Z: deflate the output with libdeflate)
+            t1 = time.perf_counter()
+            q = subprocess.run([cli, "call", "-c", ctx, fl, src, dst + fl], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
+            more[fl] = {"wall_s": time.perf_counter() - t1, "exit": q.returncode,
+                        "bam_out_MB": os.path.getsize(dst + fl) / 1e6 if q.returncode == 0 else None}
         st = {}
         for line in p.stderr.splitlines():
             if "##" in line and ":" in line:
@@ -195,16 +204,29 @@ def end_to_end(slabs, n_reads, ctx="cpg,chg,chh"):
                 "sites": sites, "bam_in_MB": os.path.getsize(src) / 1e6, "bam_out_MB": os.path.getsize(dst) / 1e6,
                 "host_threads": host_cores(), "flags": "defaults (-b 10000, -l 1000, all contexts, -z 6)",
                 "command": "hifimeth-hip call IN.bam OUT.bam", "bam_build_s": t_build,
+                "with_flag": {k: dict(v, value=sites / v["wall_s"]) for k, v in more.items()},
                 "note": "whole command incl. process and engine start-up; BGZF level-1 input, level-6 output"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def make_slabs(n, reads, seed):
+WORKLOADS = {
+    # BASELINE.json configs[2]: 30x Arabidopsis-size, GC 0.36, i.i.d. bases; 20 steps of 11 700 reads cover it in full
+    "arabidopsis": {"gc": 0.36, "cpg_oe": 1.0, "steps": 20, "total_sites": 1.1e9,
+                    "what": "BASELINE.json configs[2] statistics (GC 0.36, i.i.d. bases, ~0.30 sites per base), all three contexts"},
+    # BASELINE.json configs[3], ONE rank's share: 1/8 of a 30x human-size input = 11.6 Gbases; GC 0.41 and CpG depleted as in a vertebrate
+    # genome (observed / expected 0.24: CpG ~1 % of the bases) -- so CpG takes the per-site kernels while CHG / CHH take the trunk
+    "human_slice": {"gc": 0.41, "cpg_oe": 0.24, "steps": 64, "total_sites": None,
+                    "what": "one rank's eighth of BASELINE.json configs[3] (30x human-size: 11.6 Gbases per rank; GC 0.41, CpG observed / "
+                            "expected 0.24), all three contexts; NO 8-GPU curve exists: this is the per-rank slice on one GPU"},
+}
+
+
+def make_slabs(n, reads, seed, gc=0.36, cpg_oe=1.0):
     """n distinct slabs of `reads` synthetic reads each (threads: numpy releases the GIL in the RNG / table passes)."""
     from hifimeth_amd.synth import synth_slab
     with ThreadPoolExecutor(max_workers=max(1, min(n, host_cores()))) as ex:
-        return list(ex.map(lambda i: synth_slab(reads, seed=seed + 7919 * i, gc=0.36), range(n)))
+        return list(ex.map(lambda i: synth_slab(reads, seed=seed + 7919 * i, gc=gc, cpg_oe=cpg_oe), range(n)))
 
 
 def stream(mc, slabs, order, keep=None):
@@ -235,7 +257,8 @@ def main():
     global GROUP_BASES
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="default: what covers the workload (20 | 64)")
+    ap.add_argument("--workload", default="arabidopsis", choices=sorted(WORKLOADS))
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=11700,
                     help="reads per slab = per step (~15 kb each); default: 20 steps cover BASELINE.json configs[2] (~1.1 G sites)")
@@ -243,11 +266,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (fp32 mode, resident slab, windows)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI run (BAM in -> BAM out, default flags)")
-    ap.add_argument("--e2e-reads", type=int, default=24000, help="reads of the synthetic BAM of the end-to-end run (24000 ~ 1.26 GB)")
+    ap.add_argument("--e2e-reads", type=int, default=96000, help="reads of the synthetic BAM of the end-to-end run (96000 ~ 5 GB: start-up amortised)")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
                     help="CNN arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (e.g. front_waves=8)")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    if args.steps is None:
+        args.steps = wl["steps"]
 
     from hifimeth_amd import MethylationCaller
     from hifimeth_amd import dist as hmdist
@@ -261,7 +287,7 @@ def main():
     on_gpu_collectives = dist is not None and backend == "nccl"
 
     n_pool = max(1, min(args.pool, args.steps + args.warmup))
-    slabs = make_slabs(n_pool, args.reads, seed=20250220 + 104729 * rank)
+    slabs = make_slabs(n_pool, args.reads, seed=20250220 + 104729 * rank, gc=wl["gc"], cpg_oe=wl["cpg_oe"])
     bases_slab = [sum(r.l_qseq for r in s if r.has_kinetics() and r.l_qseq >= 1000) for s in slabs]
     from hifimeth_amd.caller import ReadBlock
     blocks = [ReadBlock(s) for s in slabs]
@@ -270,11 +296,13 @@ def main():
     mc = MethylationCaller(device=local_rank % max(ndev, 1), timing=True)
     mc.set_option("precision", args.precision)
     mc.stage_threads = max(1, min(8, host_cores() // max(1, min(world, 8)) // 2))
+    trunk_impl = 3
     for kv in args.opt:
         k, v = kv.split("=")
         mc.set_option(k, int(v))
-        if k == "group_bases":
-            GROUP_BASES = int(v)
+        if k == "trunk_impl":
+            trunk_impl = int(v)
+    GROUP_BASES = int(mc.timing()["group_bases"])   # the engine's group size in force (default: sized from free device memory)
 
     def barrier():
         if dist is not None:
@@ -387,21 +415,34 @@ def main():
             # (16 384 FLOP per v_mfma_f32_16x16x32_f16; per 112-position tile 9 / 9 / 8 / 7 position tiles of 16 rows, conv1
             # one stacked product over 6 | 7 k-blocks, conv2..conv4 three split-half products over 12 k-blocks).
             launches = sum(tm["trunk_launches"])
-            achieved = flop_front_sites(sites_ctx) / (trunk_ms * 1e-3) / 1e12
-            mfma_tile = {0: 9 * 6 * 8 + (9 + 8) * 36 * 8 + 7 * 36 * 6, 2: 9 * 7 * 8 + (9 + 8) * 36 * 8 + 7 * 36 * 6}
-            mfma_tile[1] = mfma_tile[0]
+            served = [sites_ctx[c] if tm["trunk_ms"][c] > 0 else 0 for c in range(3)]   # (a sparse context may take the per-site kernels)
+            algorithmic = flop_front_sites(served) / (trunk_ms * 1e-3) / 1e12
+            # MFMAs per 112-position tile: position tiles of 16 rows x channel tiles x k-blocks (conv1: one stacked product over 6 | 7
+            # k-blocks; conv2..conv4: three split-half products over 12 k-blocks).  trunk3 (sliding window): 7 position tiles in every
+            # layer; trunk2: 9 / 9 / 8 / 7 (the halo recomputed per tile).  (Warm-up steps -- one per read and view, < 1 % -- not counted.)
+            rows = (7, 7, 7, 7) if trunk_impl == 3 else (9, 9, 8, 7)
+            mfma_tile = {c: rows[0] * (6 if c < 2 else 7) * 8 + (rows[1] + rows[2]) * 36 * 8 + rows[3] * 36 * 6 for c in range(3)}
             executed = sum(tm["trunk_positions"][c] / 112.0 * mfma_tile[c] * 16384.0 for c in range(3)) / (trunk_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "unit": "TFLOP/s", "achieved": achieved, "peak": peak, "frac": achieved / peak,
+            kname = ("trunk3_kernel (sliding window over consecutive tiles: every layer computes 112 rows per tile, the right-hand rows kept in LDS)"
+                     if trunk_impl == 3 else "trunk2_kernel")
+            # `achieved` / `frac` are the EXECUTED figures -- MFMA FLOPs the kernel issued / its time, against the dense fp16 MFMA peak: the
+            # hardware fraction.  The reference's per-site conv1..conv4 FLOPs for the sites served divided by the same time
+            # is given as `algorithmic`: the dense form shares work between sites, so that figure can exceed the peak for a launch and is
+            # not a roofline fraction.
+            roof = {"bound": "mfma", "unit": "TFLOP/s", "achieved": executed, "peak": peak, "frac": executed / peak,
                     "avg_launch_ms": trunk_ms / launches, "launches": launches,
-                    "executed": executed, "frac_executed": executed / peak,
+                    "executed": executed, "frac_executed": executed / peak, "utilisation": executed / peak,
+                    "algorithmic": algorithmic, "algorithmic_over_peak": algorithmic / peak,
                     "algorithmic_flops_per_site": {"CpG": 2 * MAC_FRONT[0], "CHG": 2 * MAC_FRONT[1], "CHH": 2 * MAC_FRONT[2]},
-                    "utilisation": executed / peak,
+                    "mfma_per_tile": mfma_tile,
                     "positions_per_site": sum(tm["trunk_positions"]) / max(1, sites_job),
-                    "kernel": "trunk2_kernel (feature rows + bn0 + conv1..conv4 as dense a-trous maps over every read position; streaming form: "
+                    "sustained_peak_random_operands": 1880.0,
+                    "frac_of_sustained": executed / 1880.0,
+                    "kernel": kname + " -- feature rows + bn0 + conv1..conv4 as dense a-trous maps over every read position; streaming form: "
                               "4 waves, a layer's weights resident in registers, positions streamed in tile groups; "
-                              "v_mfma_f32_16x16x32_f16 split-half x3, fp32 accumulate); `achieved` = the reference's conv1..conv4 "
-                              "FLOPs for the sites served / kernel time, `executed` = MFMA FLOPs issued / kernel time; "
-                              "`utilisation` = executed / peak is the hardware figure, `frac` credits the work the dense form avoids"}
+                              "v_mfma_f32_16x16x32_f16 split-half x3, fp32 accumulate.  `achieved` = `executed` = MFMA FLOPs issued / kernel time; "
+                              "`algorithmic` = the reference's conv1..conv4 FLOPs for the sites served / kernel time; "
+                              "`sustained_peak_random_operands`: what a pure MFMA loop holds on this chip on random data (profiles/r04_mfma_shapes.txt)"}
             roof.update(quoted_traffic(tm, launches, sites_job))
         else:
             front_launches = sum(tm["front_launches"])
@@ -440,18 +481,22 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {0: "f32", 1: "f16x3+f32acc"}[args.precision],
-            "cnn_path": "dense trunk (conv1..conv4 once per read position) + per-site edge rows + tail" if trunk_ms > 0
-                        else "per site (front + tail kernels)",
+            "cnn_path": ("dense trunk (conv1..conv4 once per read position) + per-site edge rows + tail" if trunk_ms > 0 and front_ms == 0
+                         else "per context: dense trunk + edge rows + tail, or per-site front + tail kernels (config.kernel_path_by_context)" if trunk_ms > 0
+                         else "per site (front + tail kernels)"),
             "data": "synthetic",
-            "config": {"workload": f"streamed: every step stages a fresh slab of {args.reads} synthetic HiFi reads (GC 0.36, ~15 kb "
-                                   "log-normal, codev1 kinetics; BASELINE.json configs[2] statistics, all three contexts) through "
+            "config": {"workload": f"{args.workload}: streamed, every step stages a fresh slab of {args.reads} synthetic HiFi reads (~15 kb "
+                                   f"log-normal, codev1 kinetics; {wl['what']}) through "
                                    "hm_batch_submit_read -> async H2D -> scan + windows + CNN -> packed D2H, double-buffered; "
                                    "staging and both copies inside the timed region",
+                       "group_bases": GROUP_BASES, "group_bytes": int(tm["group_bytes"]),
+                       "kernel_path_by_context": {n: ("dense trunk" if tm["trunk_ms"][c] > 0 else "per site") for c, n in enumerate(("CpG", "CHG", "CHH"))},
                        "reads_per_step": args.reads, "distinct_slabs": n_pool, "staging_threads": mc.stage_threads,
                        "bases_per_gpu": int(bases_job), "sites_per_gpu": int(sites_job),
                        "sites_per_gpu_step": int(sites_job / max(1, args.steps)),
                        "timed_region_s": dt_max,
-                       "fraction_of_configs2": sites_all / CONFIG2_SITES,
+                       "fraction_of_configs2": sites_all / CONFIG2_SITES if args.workload == "arabidopsis" else None,
+                       "fraction_of_configs3_rank_slice": bases_job / 11.6e9 if args.workload == "human_slice" else None,
                        "sites_by_context": {"CpG": sites_ctx[0], "CHG": sites_ctx[1], "CHH": sites_ctx[2]},
                        "parallelism": f"read-sharded x{world}, no collective"},
             "roofline": roof,
@@ -461,7 +506,7 @@ def main():
         out.update(extras)
         if world == 1 and not args.no_extras and not args.no_e2e:
             mc.close()   # the CLI is a process of its own on the same device
-            out["end_to_end"] = end_to_end(slabs, args.e2e_reads)
+            out["end_to_end"] = end_to_end(slabs, args.e2e_reads, extra_flags=("-Z",))
         if want_parity and streamed:
             what = (f"(records taken from the STREAMED run of that slab: reads of trunk groups 0, {n_groups // 2} and {n_groups - 1} "
                     f"of its {n_groups} groups per context) ")

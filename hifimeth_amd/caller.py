@@ -85,6 +85,15 @@ class MethylationCaller:
     def set_option(self, key: str, value: int):
         self._check(self._L.hm_set_option(self._h, key.encode(), int(value)), f"hm_set_option({key})")
 
+    def new_sample(self):
+        """Forget the kernel-path choice of the previous input.  With the default option trunk = 2 the engine decides ONCE, from the
+        site density of the first non-empty batch it is given, which contexts run conv1..conv4 as the dense trunk and which per site,
+        and keeps that for its lifetime (so that the calls of one input never depend on batch cuts or host timing: the two paths
+        agree to ~1e-5 in p, not bit for bit).  A caller that reuses one engine for several samples calls this between them --
+        a CpG-poor first sample would otherwise leave the per-site kernels in force for a dense one.  (Same as setting "trunk" to 2
+        again; front ends that shard ONE input over several engines set "trunk_mask" from the head of the file instead.)"""
+        self.set_option("trunk", 2)
+
     # -- staging (EvalKmerFeaturesGenerator::init) ------------------------------------------------
     @staticmethod
     def _read_args(read):

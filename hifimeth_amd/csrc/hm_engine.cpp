@@ -1373,7 +1373,7 @@ int hm_get_timing(hm_engine_t* e, hm_timing_t* t) {
     if (!e || !t) return HM_EINVAL;
     std::lock_guard<std::mutex> lk(e->mu);
     *t = e->acc;
-    t->group_bases = e->group_bases > 0 ? e->group_bases : e->group_bases_eff;
+    t->group_bases = effective_group_bases(e);  // (sized from free device memory now if no read has been staged yet)
     t->group_bytes = 0;
     for (const DevBuf* d : {&e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4, &e->d_rowlist, &e->d_edge4, &e->d_e4row, &e->d_x6, &e->d_dump})
         t->group_bytes += (int64_t)d->cap;

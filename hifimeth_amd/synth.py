@@ -164,12 +164,21 @@ def _quantile_table(k: float, theta: float, hi: int, dtype):
 
 def synth_slab(n_reads: int, seed: int = 20250220, gc: float = 0.36, median_len: int = 15000, sigma: float = 0.35,
                min_len: int = 1000, max_len: int = 30000, frac_wide: float = 0.01, frac_short: float = 0.005,
-               frac_missing: float = 0.001, genome_len: int = 4_000_000) -> List[Read]:
+               frac_missing: float = 0.001, genome_len: int = 4_000_000, cpg_oe: float = 1.0) -> List[Read]:
     """Same statistics as synth_reads, generated slab-at-a-time for the streaming benchmark: read
-    placement, strands and the kinetics of ALL reads come from a few vectorised RNG calls; the reads are views."""
+    placement, strands and the kinetics of ALL reads come from a few vectorised RNG calls; the reads are views.
+    cpg_oe < 1 depletes CpG the way vertebrate genomes are (observed / expected CpG ~ 0.2 - 0.25 in human): that fraction of the
+    i.i.d. genome's CG dinucleotides stays, the others become TG or CA (the deamination products) -- at GC 0.41 and cpg_oe 0.24
+    CpG sites are ~1 % of the bases, below the density at which a context takes the dense trunk (hm_engine.cpp)."""
     rng = np.random.default_rng(seed)
     p = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])
     genome = rng.choice(4, size=genome_len, p=p).astype(np.uint8)
+    if cpg_oe < 1.0:
+        cg = np.nonzero((genome[:-1] == 1) & (genome[1:] == 2))[0]
+        kill = cg[rng.random(len(cg)) >= cpg_oe]
+        half = rng.random(len(kill)) < 0.5
+        genome[kill[half]] = 3          # CG -> TG
+        genome[kill[~half] + 1] = 0     # CG -> CA
     L = np.clip(rng.lognormal(np.log(median_len), sigma, n_reads), min_len, max_len).astype(np.int64)
     short = rng.random(n_reads) < frac_short
     L[short] = rng.integers(50, min_len, int(short.sum()))

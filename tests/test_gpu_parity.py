@@ -648,6 +648,28 @@ def test_resident_tail_is_byte_identical_to_the_streaming_tail():
 
 
 @pytest.mark.gpu
+def test_human_like_reads_mix_the_per_site_and_the_trunk_path_in_one_engine(oracle, oracle_models):
+    """BASELINE.json configs[3] statistics (bench.py --workload human_slice: GC 0.41, CpG depleted to observed / expected 0.24 -> ~1 %
+    of the bases): with the default options CpG takes the per-site kernels while CHG and CHH take the dense trunk, in the same engine
+    and the same batch -- the calls of all three contexts hold the 1e-4 bar against the oracle, in the order the reference writes
+    them (mod_main.cpp:217-251), also when a second slab follows through the batch pipeline."""
+    from hifimeth_amd import MethylationCaller
+    from hifimeth_amd.synth import synth_slab
+    reads = synth_slab(10, seed=97, gc=0.41, cpg_oe=0.24, median_len=6000, sigma=0.4, frac_wide=0.2)
+    with MethylationCaller(device=0, timing=True) as m:
+        calls = m.call(reads).copy()
+        t = m.timing()
+        again = m.call(reads).copy()
+    assert t["front_launches"][0] > 0 and t["trunk_launches"][0] == 0, "CpG (1 % of the bases) takes the per-site kernels"
+    assert t["trunk_launches"][1] > 0 and t["trunk_launches"][2] > 0 and t["front_launches"][1] == 0 and t["front_launches"][2] == 0
+    assert calls.tobytes() == again.tobytes()
+    n, nml, worst = _check_calls(calls, reads, oracle, oracle_models, 7)
+    by_ctx = [int((calls["ctx"] == c).sum()) for c in range(3)]
+    assert n == len(calls) and min(by_ctx) > 100 and by_ctx[0] < 0.02 * sum(r.l_qseq for r in reads), by_ctx
+    print(f"human-like mix: {by_ctx} sites per context, max|dp|={worst:.2e}, ML bytes off by one: {nml}")
+
+
+@pytest.mark.gpu
 def test_two_engines_on_one_device_fit_at_the_default_group_size():
     """VERDICT r03 #6 / ADVICE r03: the default group size is taken from the device's FREE memory (a quarter of it at most for a group's
     maps, edge rows and row lists, at most 16 Mi bases), so two engines on one device -- or ranks sharing a GPU -- cannot run it out of

@@ -62,10 +62,22 @@ def test_windows_match_reference_python(oracle):
         assert np.array_equal(s, z["strand"][sel])
         assert np.array_equal(w, z["windows"][sel])          # bit-exact
         n += len(sel)
-    assert n == len(z["windows"]) >= 60
+    assert n == len(z["windows"]) >= 85
     # fixture must exercise both clipped ends and both strands
     assert (z["windows"][:, 0, :].sum(axis=1) == 0).any() and (z["windows"][:, 400, :].sum(axis=1) == 0).any()
     assert set(z["strand"].tolist()) == {0, 1}
+    # ... and every codev1 code, in all four kinetic channels, on both strands, at both read ends (the reference assembler divides in
+    # float64 and casts, inference divides in fp32: a code whose quotients differed would break the bit-exact comparison above)
+    lut = (oracle.codev1_table().astype(np.float32) / np.float32(952))
+    assert len(set(lut.tolist())) == 256
+    W = z["windows"]
+    left, right = W[:, 0, :].sum(axis=1) == 0, W[:, 400, :].sum(axis=1) == 0   # clipped at the read's start / end
+    for strand in (0, 1):
+        for end in (left, right):
+            sel = (z["strand"] == strand) & end
+            for ch in range(4, 8):
+                seen = set(np.unique(W[sel][:, :, ch]).tolist())
+                assert set(lut.tolist()) <= seen, (strand, ch, len(seen))
 
 
 def test_codec_tables(oracle):

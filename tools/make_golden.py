@@ -73,6 +73,23 @@ def make_windows():
     kin = [np.clip(np.rint(rng.gamma(2.0, 12.0, L)), 0, 255).astype(np.uint8) for _ in range(4)]
     kin[0][:8] = [0, 63, 64, 127, 128, 191, 192, 255]  # all four codec segments incl. boundaries
     reads.append(Read("short", L, 4, pack_codes(codes), *kin))
+    # codec sweep (round 4): every codev1 code 0..255 in each of the four kinetics arrays within 256 bases of BOTH
+    # read ends, and C and G sites 100 bases from each end -- so that windows of both strands, at both ends, hold every code in all
+    # four kinetic channels.  The training assembler divides in float64 and casts (sample_dataset.py:49), inference divides in fp32
+    # (eval_kmer_features.cpp:46-60): this is where a code whose two quotients differ would show.
+    L = 700
+    codes = rng.choice(4, L).astype(np.uint8)
+    for q, c in ((96, 1), (104, 2), (L - 105, 1), (L - 97, 2), (3, 1), (5, 2), (L - 6, 1), (L - 4, 2)):
+        codes[q] = c
+    kin = []
+    for ph in (0, 67, 131, 199):
+        a = np.zeros(L, np.uint8)
+        a[:256] = (np.arange(256) + ph) % 256
+        a[L - 256:] = (np.arange(256)[::-1] + 3 * ph) % 256
+        a[256:L - 256] = rng.integers(0, 256, L - 512)
+        kin.append(a)
+    reads.append(Read("codec_sweep", L, 4, pack_codes(codes), *kin))
+    sweep_sites = {len(reads) - 1: [96, 104, L - 105, L - 97, 3, 5, L - 6, L - 4]}
     packs = dict(n_reads=len(reads))
     all_w, all_s, all_q, all_r = [], [], [], []
     for ri_, rd in enumerate(reads):
@@ -89,7 +106,7 @@ def make_windows():
         offsets = np.array([(0, 0, L, -1, -1)], dtype=[('offset', np.int64), ('id', np.int32), ('size', np.int32),
                                                         ('fn', np.int32), ('rn', np.int32)])
         cg = np.nonzero((codes == 1) | (codes == 2))[0]
-        pick = np.unique(np.concatenate([cg[:6], cg[-6:], rng.choice(cg, 6, replace=False)]))
+        pick = np.unique(np.concatenate([cg[:6], cg[-6:], rng.choice(cg, 6, replace=False), np.array(sweep_sites.get(ri_, []), np.int64)]))
         samples = np.array([[0, q, 1] for q in pick], dtype=np.uint64)
         for i in range(len(pick)):
             F, _ = SD.assemble_one_sample_features(feats, samples, offsets, 401, i)
@@ -572,6 +589,9 @@ if __name__ == "__main__":
         raise SystemExit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "thresholds":  # only the pileup threshold fixture
         make_pileup_thresholds()
+        raise SystemExit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "windows":    # only the window fixture (the CNN fixtures keep the windows they were made from)
+        make_windows()
         raise SystemExit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "chg":        # only the CHG CNN fixture (windows are those of cnn_CpG.npz)
         make_cnn_chg(np.load(os.path.join(GOLD, "cnn_CpG.npz"))["windows"])
