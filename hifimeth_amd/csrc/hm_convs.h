@@ -93,7 +93,8 @@ __device__ __forceinline__ void sconv_load_bias(const float* __restrict__ bias, 
 // Copy: the rows of THIS layer's input planes that must also reach HBM (the map rows an edge chain reads) leave from here,
 // as whole 512-byte rows: CS fixed slots per wave, two rows per slot (one ds_read_b128 + one global_store_dwordx4 per lane,
 // the store one k-block behind its read), row numbers from a list in LDS that is padded with a row that is always valid.
-// T0: the first 16-row tile of this wave's share of the positions.  RM: row map (DenseRows / SiteRows).
+// T0: the first 16-row tile of this wave's share of the positions.  RM: row map (DenseRows / SiteRows, or a map with state --
+// a row list in LDS, hm_trunk3.hip -- passed as `rm`).
 template <class C, class CN, class RM, int T0, int... GS>
 struct SConvR {
     static constexpr int NG = sizeof...(GS);
@@ -115,7 +116,7 @@ struct SConvR {
     template <int J0 = 0, class Epi, class Copy = NoCopy>
     static __device__ __forceinline__ void run(const half_t* __restrict__ in_hi, const half_t* __restrict__ in_lo, WRegs& W,
                                                Epi epi, const half_t* __restrict__ wnext, const float* __restrict__ bnext,
-                                               int nt0, int nt0n, Copy cp = Copy{}) {
+                                               int nt0, int nt0n, Copy cp = Copy{}, RM rm = RM{}) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
@@ -124,7 +125,7 @@ struct SConvR {
         int aoff[RM::DENSE ? 1 : NTILES];  // per tile: this lane's row in the input planes (site-stacked layers)
         if constexpr (!RM::DENSE) {
 #pragma unroll
-            for (int t = 0; t < NTILES; ++t) aoff[t] = RM::template off<C>((T0 + t) * 16 + li);
+            for (int t = 0; t < NTILES; ++t) aoff[t] = rm.template off<C>((T0 + t) * 16 + li);
         }
         f32x4 acc[2][GMAX][NTW];
         half8 x[XS][GMAX][2];

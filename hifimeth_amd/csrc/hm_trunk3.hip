@@ -36,8 +36,33 @@ constexpr int T3_S3 = T3_H3, T3_S2 = T3_S3 + T3_H2, T3_S1 = T3_S2 + T3_H1;  // f
 constexpr int T3_AROWS = T3_M + T3_H3, T3_BROWS = T3_M + T3_H2;             // plane A: E1 (116 rows) | E3 (128 rows); plane B: E2 (120 rows)
 constexpr int T3_XROWS = 128;                       // feature rows of a step: 112 + K1 - 1 <= 124
 constexpr int T3_LDS_HALVES = 2 * T3_AROWS * TR_RS + 2 * T3_BROWS * TR_RS + 2 * (T3_H1 + T3_H3) * TR_RS;
-constexpr int T3_RL = 3 * TR_OWN;                   // bytes of a step's row lists (rowlist3_kernel)
-static_assert(T3_M % 16 == 0 && T3_RL % 4 == 0 && T3_XROWS >= T3_M + 12, "tile plan");
+// a step's record (rowlist3_kernel): three lists of TR_OWN plane-row numbers (the E1 / E2 / E3 rows an edge chain reads), the list of
+// the E4 rows some site's tail reads (T3_N4 entries, meaningful when there are at most that many) and their number
+constexpr int T3_N4 = 64, T3_RL3 = 3 * TR_OWN, T3_RL = T3_RL3 + T3_N4 + 4;
+constexpr int T3_RLW = 3 * 32 + T3_N4 / 4 + 1;      // words of a step's record in LDS: lists at 128-byte strides, the E4 list, its count
+static_assert(T3_M % 16 == 0 && T3_RL % 4 == 0 && T3_RL / 4 <= 256 && T3_XROWS >= T3_M + 12, "tile plan");
+
+// conv4 over the NEEDED rows only: row m of the list -> plane A row rows[m] (its taps 8 and 16 rows further on), map row rows[m].
+// A site reads E4 at off - 215 + 16 s, s = 1 .. 23: at the site densities of CpG and CHG (~3 % of the positions) about half of a
+// tile's 112 rows are never read, and four m-tiles of listed rows replace seven.
+struct ListRows4 {
+    static constexpr bool DENSE = false;
+    static constexpr int M = T3_N4;
+    const uint8_t* rows = nullptr;  // LDS
+    template <class C>
+    __device__ __forceinline__ int off(int m) const { return (int)rows[m] * C::IRS; }
+};
+struct EpiE4L {
+    half_t* __restrict__ g;
+    const uint8_t* rows;  // LDS
+    __device__ __forceinline__ void operator()(int m, int col, const f32x4& acc) const {
+        half4 h, l;
+        split4(acc, h, l);
+        const size_t o = (size_t)rows[m] * (2 * C4_CH) + col;
+        *reinterpret_cast<half4*>(g + o) = h;
+        *reinterpret_cast<half4*>(g + o + C4_CH) = l;
+    }
+};
 
 struct EpiTrunk3 {  // ReLU + split -> LDS planes, row m of the NEW rows (the pointers are offset by the kept rows)
     half_t* hi;
@@ -94,7 +119,8 @@ __global__ __launch_bounds__(128) void rowlist3_kernel(const TrunkTile* __restri
     uint8_t* out = rowlist + (size_t)blk * T3_RL;
     constexpr int first_new[3] = {T3_H1, T3_H2, T3_H3}, shift[3] = {T3_S1, T3_S2, T3_S3};
     if (blk == 2 * n_work) {
-        for (int i = r; i < T3_RL; i += 128) out[i] = (uint8_t)(first_new[i / TR_OWN] + TR_OWN - 1);
+        for (int i = r; i < T3_RL3; i += 128) out[i] = (uint8_t)(first_new[i / TR_OWN] + TR_OWN - 1);
+        if (r == 0) *reinterpret_cast<uint32_t*>(out + T3_RL3 + T3_N4) = 255u;
         return;
     }
     const bool warm = blk >= n_work;
@@ -123,21 +149,48 @@ __global__ __launch_bounds__(128) void rowlist3_kernel(const TrunkTile* __restri
             f |= (site_at(x - G::LEFT) | site_at(x - G::R3) | (G::PAD4 ? 0 : site_at(x - G::R3 - 8))) << 2;
         }
     }
-    for (int i = r; i < T3_RL; i += 128) out[i] = (uint8_t)(first_new[i / TR_OWN] + TR_OWN - 1);
+    for (int i = r; i < T3_RL3; i += 128) out[i] = (uint8_t)(first_new[i / TR_OWN] + TR_OWN - 1);
+    // E4 rows some site of this context reads: position x is row s of the site at x + 215 - 16 s (s = 1 .. 23: rows 0 and 24 are the edge
+    // kernel's).  The site flags of the window come through LDS: 23 lookups per position.  Not for CHH (K1 = 13: at its density nearly every
+    // row is read) nor for warm-up steps (their E4 rows go to the dump): a count of 255 keeps the step on all 112 rows.
+    __shared__ uint8_t sf[512];
+    int need4 = 0;
+    const bool want4 = K1 == 11 && !warm;
+    if (want4) {
+        constexpr int W0 = 215 - 16 * 23;  // first site offset (relative to u) any row of the tile can belong to: -153
+        for (int i = r; i < TR_OWN + 16 * 22 + 1; i += 128) sf[i] = (uint8_t)site_at(u + W0 + i);
+    }
     uint64_t bal[3];
 #pragma unroll
     for (int l = 0; l < 3; ++l) bal[l] = __ballot((f >> l) & 1);
     if (r < 3) cnt0[r] = 0;
     __syncthreads();  // also orders the fill before the entries below (same block, global memory)
+    if (want4 && r < TR_OWN) {
+        constexpr int W0 = 215 - 16 * 23;
+#pragma unroll
+        for (int sidx = 1; sidx <= 23; ++sidx) need4 |= sf[r + 215 - 16 * sidx - W0];
+    }
+    const uint64_t bal4 = __ballot(need4);
+    __shared__ int cnt4[2];
     if (r == 0) {
 #pragma unroll
         for (int l = 0; l < 3; ++l) cnt0[l] = __popcll(bal[l]);
     }
+    if ((r & 63) == 0) cnt4[r >> 6] = __popcll(bal4);
     __syncthreads();
     const int lane = r & 63;
 #pragma unroll
     for (int l = 0; l < 3; ++l)
         if ((f >> l) & 1) out[l * TR_OWN + (r >= 64 ? cnt0[l] : 0) + __popcll(bal[l] & ((1ull << lane) - 1))] = (uint8_t)(first_new[l] + r);
+    // the E4 list: the needed rows in ascending order, filled up with the first of them (a row is stored twice: harmless)
+    const int n4 = want4 ? cnt4[0] + cnt4[1] : 255;
+    if (want4 && n4 <= T3_N4) {
+        const int at = (r >= 64 ? cnt4[0] : 0) + __popcll(bal4 & ((1ull << lane) - 1));
+        if (need4) out[T3_RL3 + at] = (uint8_t)r;
+        __syncthreads();
+        if (r >= n4 && r < T3_N4) out[T3_RL3 + r] = n4 > 0 ? out[T3_RL3] : (uint8_t)0;
+    }
+    if (r == 0) *reinterpret_cast<uint32_t*>(out + T3_RL3 + T3_N4) = (uint32_t)n4;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -148,7 +201,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     constexpr int NW = 4, NTW = 2;
     __shared__ __attribute__((aligned(16))) half_t smem[T3_LDS_HALVES + T3_XROWS * TR_WRS];
     static_assert(sizeof(smem) == 147840, "LDS plan");
-    __shared__ uint32_t rlist[2][3 * 32];  // the step's row lists ([3][128] bytes); two buffers: conv4 still copies E3 rows while the next step's arrive
+    __shared__ uint32_t rlist[2][T3_RLW];  // the step's record ([3][128] bytes of row lists, the E4 list, its count); two buffers: conv4 still reads one while the next step's arrives
     __shared__ int64_t s_grow0;
     __shared__ int s_warm;
     half_t* a_hi = smem;
@@ -168,7 +221,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     if (w0 >= w1) return;
 
     for (int i = threadIdx.x; i < (T3_LDS_HALVES + T3_XROWS * TR_WRS) / 2; i += NW * 64) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
-    if (threadIdx.x < 2 * 3 * 32) rlist[0][threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < 2 * T3_RLW; i += NW * 64) rlist[0][i] = 0;
     __syncthreads();
 
     // The next step's feature rows and row lists, one row per thread, in steps that sit between the layers so that no load's
@@ -219,7 +272,8 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
             const bool in = x >= 0 && x < bd.ri.len;
             *reinterpret_cast<uint4*>(xb + r * TR_WRS) = feature_row(in ? bd.b : -1, bd.k, bd.view);
         }
-        if (r < T3_RL / 4) rlist[buf][r / (TR_OWN / 4) * 32 + r % (TR_OWN / 4)] = bd.rl;
+        if (r < T3_RL3 / 4) rlist[buf][r / (TR_OWN / 4) * 32 + r % (TR_OWN / 4)] = bd.rl;
+        else if (r < T3_RL / 4) rlist[buf][3 * 32 + r - T3_RL3 / 4] = bd.rl;   // the E4 list and its count
     };
 
     using C1 = SCfg<8, (2 * K1 + 3) / 4 * 4, TR_WRS, 1, true, false, K1, 2, NTW>;
@@ -281,6 +335,21 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         move_rows<T3_H2, NW * 64>(b_hi, b_lo, b_hi + T3_M * TR_RS, b_lo + T3_M * TR_RS, threadIdx.x);
         // a warm-up step's E4 rows are not results (its kept rows were not): they go to the dump
         const EpiE43 e4{cur_warm ? dump : reinterpret_cast<half_t*>(mp.e4) + grow0 * (2 * C4_CH)};
+        const int n4 = __builtin_amdgcn_readfirstlane((int)rlist[buf][T3_RLW - 1]);
+        if (!cur_warm && n4 <= T3_N4) {
+            // ---- conv4 over the listed rows only: four m-tiles of needed rows instead of seven of all (CpG / CHG at their usual densities) ----
+            const uint8_t* rows4 = rl + 3 * 128;
+            const ListRows4 rm{rows4};
+            const EpiE4L e4l{reinterpret_cast<half_t*>(mp.e4) + grow0 * (2 * C4_CH), rows4};
+            using NoCp = typename SConvR<C4, C1, ListRows4, 2, 2>::NoCopy;
+            if (wave & 1) {  // a = resident tile 1 alone on list tiles 0, 1 (with the E3 copy slots), the pair on list tiles 2, 3
+                SConvR<C4s, void, ListRows4, 0, 1, 1>::template run<1>(a_hi, a_lo, wr, e4l, c1f, W.c1f_bias, nt04, nt0, CopyRows3<NW>{rl + 256, g3}, rm);
+                SConvR<C4, C1, ListRows4, 2, 2>::run(a_hi, a_lo, wr, e4l, c1f, W.c1f_bias, nt04, nt0, NoCp{}, rm);
+            } else {         // the pair on list tiles 0, 1, a = resident tile 0 alone on list tiles 2, 3
+                SConvR<C4, void, ListRows4, 0, 1, 1>::run(a_hi, a_lo, wr, e4l, c1f, W.c1f_bias, nt04, nt0, CopyRows3<NW>{rl + 256, g3}, rm);
+                SConvR<C4s, C1, ListRows4, 2, 2>::template run<0>(a_hi, a_lo, wr, e4l, c1f, W.c1f_bias, nt04, nt0, NoCp{}, rm);
+            }
+        } else
         // the four-tile part first (it carries the E3 copy slots), the three-tile part last (behind it the next step's conv1
         // weights are fetched into the registers it frees)
         if (wave & 1) {  // a = resident tile 1 alone on position tiles 0 .. 3, the pair on tiles 4 .. 6
@@ -299,7 +368,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     (void)warm;
 }
 
-size_t trunk3_rowlist_bytes(int64_t n_work) { return (size_t)(2 * n_work + 1) * T3_RL; }
+size_t trunk3_rowlist_bytes(int64_t n_work) { return (size_t)(2 * n_work + 1) * T3_RL + 64; }
 size_t trunk3_dump_bytes() { return (size_t)TR_OWN * 2 * C4_CH * sizeof(uint16_t); }
 
 void launch_trunk3(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,

@@ -1,7 +1,7 @@
-"""Derived per-kernel figures from a rocprofv3 --pmc summary written by tools/prof_r03.sh (pmc_summary.txt):
-   python tools/pmc_derive.py gpurun_out/prof_r03/pmc_summary.txt [bench.json of the PMC run] [traffic.json to write] > profiles/r03_pmc_derived.txt
-With the two optional arguments the HBM-side bytes of trunk2_kernel are also written per VIEW POSITION (bytes per launch / the
-positions a launch of that context covered in the profiled run): what bench.py quotes as roofline.traffic.
+"""Derived per-kernel figures from a rocprofv3 --pmc summary written by tools/prof_r04.sh (pmc_summary.txt):
+   python tools/pmc_derive.py gpurun_out/prof_r04/pmc_summary.txt [bench.json of a PMC pass] [traffic.json to write] [commit] > profiles/r04_pmc_derived.txt
+With the optional arguments the HBM-side bytes of the trunk kernel are also written per VIEW POSITION (bytes per launch / the
+positions a launch of that context covered in the profiled run): what bench.py gives as roofline.traffic_quoted.
 GRBM_GUI_ACTIVE sums the 8 XCDs; the SQ counters sum all 1024 SIMDs -> MFMA busy = MFMA_BUSY / (GUI_ACTIVE / 8 * 1024).
 FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled (gfx950 counts 128-byte requests as 64 B: MI355X_MICROARCH.md,
 HBM section)."""
@@ -13,7 +13,7 @@ for line in open(sys.argv[1]):
     f = line.rstrip("\n").split("\t")
     if len(f) >= 6:
         d[f[0]][f[1]] = (float(f[3]), int(f[5]))
-print("# derived from", sys.argv[1].split("/")[-1], "(rocprofv3 --pmc, one counter group per run, bench.py --steps 1 --warmup 1 --reads 2000)")
+print("# derived from", sys.argv[1].split("/")[-1], "(rocprofv3 --pmc, one counter group per run, over the DRIVER's configuration: bench.py --steps 2 --warmup 1, full-size slabs, default options)")
 print("# GRBM_GUI_ACTIVE sums the 8 XCDs (8 x 2.1 GHz x launch time); SQ counters sum all 1024 SIMDs -> MFMA busy = MFMA_BUSY / (GUI_ACTIVE / 8 * 1024)")
 print("# FETCH_SIZE / WRITE_SIZE in KB; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B: MI355X_MICROARCH.md, HBM section)")
 for k, c in sorted(d.items()):
@@ -22,7 +22,7 @@ for k, c in sorted(d.items()):
     g = lambda n: c.get(n, (0.0, 0))[0]  # noqa: E731
     gui, mf = g("GRBM_GUI_ACTIVE"), g("SQ_INSTS_MFMA")
     wc = max(g("SQ_WAVE_CYCLES"), 1.0)
-    k = "tail_kernel_h<0, GATHER>" if "PKDF16" in k else k.replace("void hm::", "")
+    k = k.replace("void hm::", "")
     k = "tail_kernel_r (resident weights)" if k == "tail_kernel_r" else k
     print(f"{k:36s} launches {c['GRBM_GUI_ACTIVE'][1]:4d}  mean launch {gui / 8 / 2.1e6:7.3f} ms(@2.1GHz)  "
           f"MFMA busy {g('SQ_VALU_MFMA_BUSY_CYCLES') / (gui / 8 * 1024):.3f}  MFMA/launch {mf:.3g}  VALU/MFMA {g('SQ_INSTS_VALU') / mf:.2f}  "
@@ -35,17 +35,20 @@ if len(sys.argv) > 3:
     b = json.load(open(sys.argv[2]))
     dm = b["device_ms_timed_region"]
     pos = [dm["trunk_positions"][c] / max(1, dm["trunk_launches"][c]) for c in range(3)]   # positions per launch, per context
-    out = {"_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over `python bench.py --steps 1 --warmup 1 "
-                      "--reads 2000 --no-extras --no-cpu-baseline`; FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B: "
-                      "MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported (calibrated for 16-B-per-lane stores; the trunk's map rows "
+    TR = ("trunk3_kernel", "trunk2_kernel")
+    kern = next((t for t in TR if any(t in k for k in d)), TR[0])
+    out = {"_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over `python bench.py --steps 2 --warmup 1 "
+                      "--no-extras --no-cpu-baseline` (the driver's full-size slabs and default options); FETCH_SIZE doubled (gfx950 tallies 128-B "
+                      "requests as 64 B: MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported (calibrated for 16-B-per-lane stores; the trunk's E4 rows "
                       "leave as 8-B-per-lane stores: uncalibrated width); Infinity-Cache hits are counted, not excluded",
-           "trunk2_kernel": {}}
+           "kernel": kern, "command": "python bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline", "commit": sys.argv[4] if len(sys.argv) > 4 else None,
+           "trunk_kernel": {}}
     for key, tag, cs in (("k11", "", (0, 1)), ("k13", "<13", (2,))):
-        c = next((v for k, v in d.items() if "trunk2_kernel" in k and k.endswith(tag) and ("<13" in k) == bool(tag)), None)
+        c = next((v for k, v in d.items() if kern in k and ("<13" in k) == bool(tag)), None)
         if c is None:
             continue
         p = sum(pos[i] for i in cs) / len(cs)
         rd, wr = 2 * c.get("FETCH_SIZE", (0, 0))[0] * 1024, c.get("WRITE_SIZE", (0, 0))[0] * 1024
-        out["trunk2_kernel"][key] = {"read_B_per_launch": rd, "write_B_per_launch": wr, "positions_per_launch": p,
-                                     "read_B_per_position": rd / p, "write_B_per_position": wr / p, "launches": c["GRBM_GUI_ACTIVE"][1] if "GRBM_GUI_ACTIVE" in c else 0}
+        out["trunk_kernel"][key] = {"read_B_per_launch": rd, "write_B_per_launch": wr, "positions_per_launch": p,
+                                    "read_B_per_position": rd / p, "write_B_per_position": wr / p, "launches": c["GRBM_GUI_ACTIVE"][1] if "GRBM_GUI_ACTIVE" in c else 0}
     json.dump(out, open(sys.argv[3], "w"), indent=1)

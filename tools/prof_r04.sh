@@ -38,7 +38,7 @@ for f in sorted(glob.glob("$O/pmc/g*/**/*counter_collection.csv", recursive=True
     for row in csv.DictReader(open(f)):
         n = row["Kernel_Name"]
         k = n.split("(")[0].split("<")[0][-28:] + ("<13" if "<13" in n or "ILi13" in n else "")
-        for t in ("tail_kernel_r", "tail_kernel_x"):
+        for t in ("tail_kernel_r", "tail_main_kernel", "tail_head_kernel"):
             if t in n:
                 k = t
         a = agg[(k, row["Counter_Name"])]
