@@ -176,7 +176,8 @@ def end_to_end(slabs, n_reads, ctx="cpg,chg,chh", extra_flags=()):
     if not os.path.exists(cli):
         return {"error": "hifimeth_amd/bin/hifimeth-hip is not built"}
     pool = [r for s in slabs for r in s]
-    reads = [pool[i % len(pool)] for i in range(n_reads)]   # (the pool cycles: a 5 GB file needs more reads than six slabs hold)
+    n_reads = min(n_reads, 2 * len(pool))   # the pool cycles at most twice (a 5 GB file needs more reads than six slabs hold)
+    reads = [pool[i % len(pool)] for i in range(n_reads)]
     tmp = tempfile.mkdtemp(prefix="hm_e2e_")
     try:
         src, dst = os.path.join(tmp, "in.bam"), os.path.join(tmp, "out.bam")
