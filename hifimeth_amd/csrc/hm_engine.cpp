@@ -132,10 +132,10 @@ struct hm_batch {
     // device
     DevBuf d_raw, d_reads, d_chunks, d_rinfo, d_tiles, d_bases, d_kin, d_sctx, d_counts, d_offs, d_totals, d_err;
     DevBuf d_usites, d_utag, d_csites, d_opos, d_logits, d_p, d_ml, d_calls;
-    int32_t* h_totals = nullptr;  // pinned [8]
+    int32_t* h_totals = nullptr;  // pinned [12]: the scan kernel's 8 totals + [8..10] the trunk's listed-row steps per context
     int32_t* h_err = nullptr;     // pinned
     PinnedArr<hm_call_t> h_calls;
-    int32_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t totals[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     std::vector<TimedSpan> spans;
 };
@@ -274,6 +274,10 @@ struct Span {
 
 // spans of finished work -> accumulated timing; `totals` gives the site counts the CNN launch windows resolved to
 void collect_timing(hm_engine* e, std::vector<TimedSpan>& spans, const int32_t* totals) {
+    if (!spans.empty() && totals) {  // once per timed run of a batch
+        std::lock_guard<std::mutex> lk(e->mu);
+        for (int c = 0; c < 3; ++c) e->acc.trunk_list_steps[c] += totals[8 + c];
+    }
     for (auto& s : spans) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
@@ -397,14 +401,14 @@ hm_batch* new_slot(hm_engine* e, int id) {
     HIP_TRY(hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&b->ev_comp, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&b->ev_out, hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 8 * sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 12 * sizeof(int32_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_err), sizeof(int32_t), hipHostMallocDefault));
-    memset(b->h_totals, 0, 8 * sizeof(int32_t));
+    memset(b->h_totals, 0, 12 * sizeof(int32_t));
     *b->h_err = 0;
-    b->d_totals.reserve(8 * sizeof(int32_t));
+    b->d_totals.reserve(12 * sizeof(int32_t));
     b->d_err.reserve(sizeof(int32_t));
     HIP_TRY(hipMemset(b->d_err.p, 0, sizeof(int32_t)));
-    HIP_TRY(hipMemset(b->d_totals.p, 0, 8 * sizeof(int32_t)));
+    HIP_TRY(hipMemset(b->d_totals.p, 0, 12 * sizeof(int32_t)));
     hm_batch* raw = b.get();
     e->slots.push_back(std::move(b));
     return raw;
@@ -592,7 +596,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
                 if (e->trunk_impl == 3)
                     launch_trunk3(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
                                   b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->d_dump.as<uint16_t>(),
-                                  e->num_cu);
+                                  b->d_totals.as<int32_t>() + 8, e->num_cu);
                 else if (e->trunk_impl)
                     launch_trunk2(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
                                   b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->num_cu, w16,
@@ -754,7 +758,7 @@ void enqueue_run(hm_batch* b) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev_comp, e->stream));
     HIP_TRY(hipStreamWaitEvent(b->s_io, b->ev_comp, 0));
-    HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals.p, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, b->s_io));
+    HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals.p, 12 * sizeof(int32_t), hipMemcpyDeviceToHost, b->s_io));
     HIP_TRY(hipMemcpyAsync(b->h_err, b->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, b->s_io));
     HIP_TRY(hipEventRecord(b->ev_out, b->s_io));
     b->ran = true;

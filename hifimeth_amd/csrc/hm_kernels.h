@@ -13,7 +13,7 @@ namespace hm {
 void launch_prep(hipStream_t st, const uint8_t* raw, const ReadDesc* reads, const Chunk* chunks, int n_chunks,
                  int ctx_mask, uint8_t* bases, uint32_t* kin, uint8_t* sctx, int32_t* chunk_counts, int32_t* err);
 // S: exclusive scan of the NCNT chunk counters -> chunk offsets [n_chunks + 1][NCNT] (last row = totals),
-//    totals[8]: CpG, CHG, CHH, all, ctx_base[3], reverse-strand sites.
+//    totals[12]: CpG, CHG, CHH, all, ctx_base[3], reverse-strand sites; [8..10] zeroed (the sliding-window trunk counts its listed-row steps there).
 void launch_scan(hipStream_t st, const int32_t* chunk_counts, int n_chunks, int32_t* chunk_offs, int32_t* totals);
 // B: emit the unified (read, qoff)-ordered site list, the per-context lists and opos[uidx] = position of the site's
 //    call in the output order (per read: forward-strand calls by qoff, then reverse-strand calls; mod_main.cpp:217-251).
@@ -95,7 +95,7 @@ size_t trunk3_rowlist_bytes(int64_t n_work);
 size_t trunk3_dump_bytes();
 void launch_trunk3(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w, const TrunkMaps& maps,
-                   uint16_t* dump, int grid);
+                   uint16_t* dump, int32_t* list_steps, int grid);
 // the same path in strict fp32 (precision 0; hm_trunk_f32.hip): fp32 maps and edge rows, v_mfma_f32_16x16x4_f32
 void launch_trunk_f32(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                       const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,

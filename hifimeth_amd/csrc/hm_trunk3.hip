@@ -134,42 +134,44 @@ __global__ __launch_bounds__(128) void rowlist3_kernel(const TrunkTile* __restri
         const int64_t j = ri.base_off + (view ? L - 1 - y : y);
         return (int)(sctx[j] == ctx && bases[j] == want_base);
     };
+    // the site flags of every position any lookup of this block can touch go through LDS once: [u - 176, u + 352)
+    constexpr int W0 = -176, WN = 528;
+    __shared__ uint8_t sf[WN];
+    for (int i = r; i < WN; i += 128) sf[i] = (uint8_t)site_at(u + W0 + i);
+    for (int i = r; i < T3_RL3; i += 128) out[i] = (uint8_t)(first_new[i / TR_OWN] + TR_OWN - 1);
+    __syncthreads();
+    auto sat = [&](int y) __attribute__((always_inline)) { return (int)sf[y - u - W0]; };   // y - u in [W0, W0 + WN)
+    static_assert(-G::R1 - 2 + T3_S1 >= W0 && -G::R2 - 4 + T3_S2 >= W0 && -G::R3 - 8 + T3_S3 >= W0 && T3_S1 + TR_OWN - 1 - G::LEFT < W0 + WN &&
+                  215 - 16 * 23 >= W0 && TR_OWN - 1 + 215 - 16 < W0 + WN, "the window covers every lookup");
     int f = 0;
     if (r < TR_OWN) {
         {
             const int x = u + shift[0] + r;
-            f |= (site_at(x - G::LEFT) | site_at(x - G::R1) | (G::PAD2 ? 0 : site_at(x - G::R1 - 2))) << 0;
+            f |= (sat(x - G::LEFT) | sat(x - G::R1) | (G::PAD2 ? 0 : sat(x - G::R1 - 2))) << 0;
         }
         {
             const int x = u + shift[1] + r;
-            f |= (site_at(x - G::LEFT) | site_at(x - G::R2) | (G::PAD3 ? 0 : site_at(x - G::R2 - 4))) << 1;
+            f |= (sat(x - G::LEFT) | sat(x - G::R2) | (G::PAD3 ? 0 : sat(x - G::R2 - 4))) << 1;
         }
         {
             const int x = u + shift[2] + r;
-            f |= (site_at(x - G::LEFT) | site_at(x - G::R3) | (G::PAD4 ? 0 : site_at(x - G::R3 - 8))) << 2;
+            f |= (sat(x - G::LEFT) | sat(x - G::R3) | (G::PAD4 ? 0 : sat(x - G::R3 - 8))) << 2;
         }
     }
-    for (int i = r; i < T3_RL3; i += 128) out[i] = (uint8_t)(first_new[i / TR_OWN] + TR_OWN - 1);
     // E4 rows some site of this context reads: position x is row s of the site at x + 215 - 16 s (s = 1 .. 23: rows 0 and 24 are the edge
-    // kernel's).  The site flags of the window come through LDS: 23 lookups per position.  Not for CHH (K1 = 13: at its density nearly every
-    // row is read) nor for warm-up steps (their E4 rows go to the dump): a count of 255 keeps the step on all 112 rows.
-    __shared__ uint8_t sf[512];
+    // kernel's).  Not for CHH (K1 = 13: at its density nearly every row is read) nor for warm-up steps (their E4 rows go to the dump): a
+    // count of 255 keeps the step on all 112 rows.
     int need4 = 0;
     const bool want4 = K1 == 11 && !warm;
-    if (want4) {
-        constexpr int W0 = 215 - 16 * 23;  // first site offset (relative to u) any row of the tile can belong to: -153
-        for (int i = r; i < TR_OWN + 16 * 22 + 1; i += 128) sf[i] = (uint8_t)site_at(u + W0 + i);
+    if (want4 && r < TR_OWN) {
+#pragma unroll
+        for (int sidx = 1; sidx <= 23; ++sidx) need4 |= sat(u + r + 215 - 16 * sidx);
     }
     uint64_t bal[3];
 #pragma unroll
     for (int l = 0; l < 3; ++l) bal[l] = __ballot((f >> l) & 1);
     if (r < 3) cnt0[r] = 0;
-    __syncthreads();  // also orders the fill before the entries below (same block, global memory)
-    if (want4 && r < TR_OWN) {
-        constexpr int W0 = 215 - 16 * 23;
-#pragma unroll
-        for (int sidx = 1; sidx <= 23; ++sidx) need4 |= sf[r + 215 - 16 * sidx - W0];
-    }
+    __syncthreads();
     const uint64_t bal4 = __ballot(need4);
     __shared__ int cnt4[2];
     if (r == 0) {
@@ -197,7 +199,8 @@ __global__ __launch_bounds__(128) void rowlist3_kernel(const TrunkTile* __restri
 template <int K1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views, int ctx, const RInfo* __restrict__ rinfo,
-                   const uint8_t* __restrict__ bases, const uint32_t* __restrict__ kin, CtxWeights W, TrunkMaps mp, half_t* __restrict__ dump) {
+                   const uint8_t* __restrict__ bases, const uint32_t* __restrict__ kin, CtxWeights W, TrunkMaps mp, half_t* __restrict__ dump,
+                   int32_t* __restrict__ list_steps) {
     constexpr int NW = 4, NTW = 2;
     __shared__ __attribute__((aligned(16))) half_t smem[T3_LDS_HALVES + T3_XROWS * TR_WRS];
     static_assert(sizeof(smem) == 147840, "LDS plan");
@@ -302,6 +305,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     build_store(0);
     int buf = 0;
     int w = w0, warm = 1;  // the step being computed
+    int n_list = 0;        // steps of this workgroup whose conv4 ran over the listed rows only
     while (true) {
         __syncthreads();  // the step's feature rows, lists and descriptors are in LDS; the previous step is through with the planes
         const int64_t grow0 = s_grow0;
@@ -337,6 +341,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         const EpiE43 e4{cur_warm ? dump : reinterpret_cast<half_t*>(mp.e4) + grow0 * (2 * C4_CH)};
         const int n4 = __builtin_amdgcn_readfirstlane((int)rlist[buf][T3_RLW - 1]);
         if (!cur_warm && n4 <= T3_N4) {
+            ++n_list;
             // ---- conv4 over the listed rows only: four m-tiles of needed rows instead of seven of all (CpG / CHG at their usual densities) ----
             const uint8_t* rows4 = rl + 3 * 128;
             const ListRows4 rm{rows4};
@@ -366,6 +371,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         warm = bd.warm;
     }
     (void)warm;
+    if (list_steps && threadIdx.x == 0 && n_list) atomicAdd(list_steps + ctx, n_list);
 }
 
 size_t trunk3_rowlist_bytes(int64_t n_work) { return (size_t)(2 * n_work + 1) * T3_RL + 64; }
@@ -373,16 +379,16 @@ size_t trunk3_dump_bytes() { return (size_t)TR_OWN * 2 * C4_CH * sizeof(uint16_t
 
 void launch_trunk3(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w, const TrunkMaps& maps,
-                   uint16_t* dump, int grid) {
+                   uint16_t* dump, int32_t* list_steps, int grid) {
     if (n_tiles <= 0) return;
     const int n_work = n_tiles * n_views;
     const dim3 g(min(n_work, grid));
     if (k1 == 11) {
         hipLaunchKernelGGL(rowlist3_kernel<11>, dim3(2 * n_work + 1), dim3(128), 0, st, tiles, n_tiles, n_work, ctx, rinfo, bases, sctx, maps.rowlist);
-        hipLaunchKernelGGL(trunk3_kernel<11>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump));
+        hipLaunchKernelGGL(trunk3_kernel<11>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps);
     } else {
         hipLaunchKernelGGL(rowlist3_kernel<13>, dim3(2 * n_work + 1), dim3(128), 0, st, tiles, n_tiles, n_work, ctx, rinfo, bases, sctx, maps.rowlist);
-        hipLaunchKernelGGL(trunk3_kernel<13>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump));
+        hipLaunchKernelGGL(trunk3_kernel<13>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps);
     }
 }
 

@@ -77,6 +77,7 @@ typedef struct {
     double trunk_ms[3], edge_ms[3]; /* dense trunk (conv1..conv4 over whole reads) and window-edge kernels */
     int64_t trunk_launches[3], edge_launches[3];
     int64_t trunk_positions[3]; /* (read, strand view) positions evaluated by the timed trunk launches */
+    int64_t trunk_list_steps[3]; /* tiles whose conv4 ran over the listed (needed) rows only: 4 m-tiles instead of 7 (sliding-window trunk) */
     int64_t group_bases;        /* bases per trunk read group in force (option "group_bases", or what the engine sized from free memory) */
     int64_t group_bytes;        /* device bytes the engine holds for a read group's maps, edge rows and hand-off buffers */
 } hm_timing_t;

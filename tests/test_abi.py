@@ -33,6 +33,22 @@ def test_struct_layout_matches_header():
     assert CALL_DTYPE.fields["p"][1] == 12 and CALL_DTYPE.fields["scaled_prob"][1] == 10
 
 
+def test_timing_struct_matches_header(tmp_path):
+    """hm_timing_t grows round by round (round 4: trunk_list_steps, group_bases, group_bytes): the ctypes mirror must keep the header's size
+    and the offsets of its last fields -- checked against what the C compiler makes of include/hifimeth_hip.h."""
+    import subprocess
+    from hifimeth_amd import _lib
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "hifimeth_hip.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu\\n", sizeof(hm_timing_t), offsetof(hm_timing_t, trunk_list_steps), '
+                   'offsetof(hm_timing_t, group_bases), offsetof(hm_timing_t, group_bytes)); return 0; }\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    size, o1, o2, o3 = (int(x) for x in subprocess.check_output([str(exe)], text=True).split())
+    T = _lib.hm_timing_t
+    assert (size, o1, o2, o3) == (ctypes.sizeof(T), T.trunk_list_steps.offset, T.group_bases.offset, T.group_bytes.offset)
+
+
 def test_no_cpu_fallback():
     """Without a GPU the product must fail loudly, never fall back to a CPU path."""
     import torch
