@@ -23,6 +23,18 @@
 //
 // Reference for what is computed: training/model_cnn.py:8-85 / models/*.onnx (mod_main.cpp:32-98).
 #include "hm_convh.h"
+#ifdef HM_TRUNK_STAMP  // diagnostic build (make stamp): per-wave shader-clock phase sums of workgroup 0, read by tools/trunk3_stamps.py
+#include "hm_stamp.h"
+namespace hm { __device__ unsigned long long g_trunk3_stamp[8][24]; }
+extern "C" int hm_debug_trunk3_stamps(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(hm::g_trunk3_stamp), sizeof(hm::g_trunk3_stamp)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[8][24];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(hm::g_trunk3_stamp), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 #include "hm_convs.h"
 #include "hm_edge.h"
 
@@ -306,8 +318,19 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     int buf = 0;
     int w = w0, warm = 1;  // the step being computed
     int n_list = 0;        // steps of this workgroup whose conv4 ran over the listed rows only
+#ifdef HM_TRUNK_STAMP
+    // per layer: [0] barrier -> run returns, [3] wait at the next barrier; slot 22 / 23: s_memtime / s_memrealtime of the whole loop
+    unsigned long long ts[10], acc_t[16] = {};
+    unsigned long long n_it = 0;
+    const bool st_on = blockIdx.x == 0;
+    const unsigned long long tk0 = hm_stamp(), tr0 = __builtin_amdgcn_s_memrealtime();
+#define TS(i) do { if (st_on) ts[i] = hm_stamp(); } while (0)
+#else
+#define TS(i)
+#endif
     while (true) {
         __syncthreads();  // the step's feature rows, lists and descriptors are in LDS; the previous step is through with the planes
+        TS(0);
         const int64_t grow0 = s_grow0;
         const int cur_warm = __builtin_amdgcn_readfirstlane(s_warm);
         // the next step
@@ -322,18 +345,24 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         move_rows<T3_H1, NW * 64>(a_hi, a_lo, h1_hi, h1_lo, threadIdx.x);
         L1::run(xb, xb, wr, EpiTrunk3{a_hi + T3_H1 * TR_RS, a_lo + T3_H1 * TR_RS}, wf(1), W.bias[1], nt0, nt0);
         build_desc1(min(wn, w1 - 1));  // unconditional (as are the loads below): the compiler's wait counts stay exact
+        TS(1);
         __syncthreads();
+        TS(2);
         build_desc2(cur_warm, false);
         L2::run(a_hi, a_lo, wr, EpiTrunk3{b_hi + T3_H2 * TR_RS, b_lo + T3_H2 * TR_RS}, wf(2), W.bias[2], nt0, nt0, CopyRows3<NW>{rl, g1});
         // E1's last rows wait in H1 for the next step (conv3 is about to overwrite them)
         move_rows<T3_H1, NW * 64>(h1_hi, h1_lo, a_hi + T3_M * TR_RS, a_lo + T3_M * TR_RS, threadIdx.x);
+        TS(3);
         __syncthreads();
+        TS(4);
         build_desc3();
         build_loads();
         // E3's kept rows come back into plane A rows 0 .. 15 (conv2 is through with them; conv3 writes rows 16 ..)
         move_rows<T3_H3, NW * 64>(a_hi, a_lo, h3_hi, h3_lo, threadIdx.x);
         L3::run(b_hi, b_lo, wr, EpiTrunk3{a_hi + T3_H3 * TR_RS, a_lo + T3_H3 * TR_RS}, wf(3), W.bias[3], nt0, nt04, CopyRows3<NW>{rl + 128, g2});
+        TS(5);
         __syncthreads();
+        TS(6);
         // E3's and E2's last rows are kept for the next step: E3's in H3 (plane A is E1's next), E2's at the top of plane B itself
         move_rows<T3_H3, NW * 64>(h3_hi, h3_lo, a_hi + T3_M * TR_RS, a_lo + T3_M * TR_RS, threadIdx.x);
         move_rows<T3_H2, NW * 64>(b_hi, b_lo, b_hi + T3_M * TR_RS, b_lo + T3_M * TR_RS, threadIdx.x);
@@ -366,11 +395,32 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         }
         build_store(buf ^ 1);
         buf ^= 1;
+        TS(7);
+#ifdef HM_TRUNK_STAMP
+        if (st_on) {
+            __syncthreads();
+            ts[8] = hm_stamp();
+            for (int l = 0; l < 4; ++l) {
+                acc_t[4 * l + 0] += ts[2 * l + 1] - ts[2 * l];
+                acc_t[4 * l + 3] += ts[2 * l + 2] - ts[2 * l + 1];
+            }
+            ++n_it;
+        }
+#endif
         if (last) break;
         w = wn;
         warm = bd.warm;
     }
     (void)warm;
+#ifdef HM_TRUNK_STAMP
+    if (st_on && (threadIdx.x & 63) == 0) {
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_trunk3_stamp[threadIdx.x >> 6][i], acc_t[i]);
+        atomicAdd(&g_trunk3_stamp[threadIdx.x >> 6][16], n_it);
+        atomicAdd(&g_trunk3_stamp[threadIdx.x >> 6][22], hm_stamp() - tk0);
+        atomicAdd(&g_trunk3_stamp[threadIdx.x >> 6][23], __builtin_amdgcn_s_memrealtime() - tr0);
+    }
+#endif
+#undef TS
     if (list_steps && threadIdx.x == 0 && n_list) atomicAdd(list_steps + ctx, n_list);
 }
 
