@@ -164,7 +164,7 @@ def quoted_traffic(tm, launches, sites):
     return out
 
 
-def end_to_end(slabs, n_reads, ctx="cpg,chg,chh", extra_flags=()):
+def end_to_end(slabs, n_reads, ctx="cpg,chg,chh", extra_flags=(), cycles=2):
     """`hifimeth-hip call IN.bam OUT.bam` with the reference's default flags (mod_options.cpp:10-17) on a synthetic BAM of
     n_reads reads: BGZF inflate -> parse -> stage -> GPU -> MM/ML tags -> deflate, engine start-up included -- the quantity
     the reference's one published figure is about (README.md:31: wall-clock of the whole command)."""
@@ -176,7 +176,7 @@ def end_to_end(slabs, n_reads, ctx="cpg,chg,chh", extra_flags=()):
     if not os.path.exists(cli):
         return {"error": "hifimeth_amd/bin/hifimeth-hip is not built"}
     pool = [r for s in slabs for r in s]
-    n_reads = min(n_reads, 2 * len(pool))   # the pool cycles at most twice (a 5 GB file needs more reads than six slabs hold)
+    n_reads = min(n_reads, cycles * len(pool))   # the pool cycles at most twice by default (a 5 GB file needs more reads than six slabs hold)
     reads = [pool[i % len(pool)] for i in range(n_reads)]
     tmp = tempfile.mkdtemp(prefix="hm_e2e_")
     try:
@@ -268,6 +268,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (fp32 mode, resident slab, windows)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI run (BAM in -> BAM out, default flags)")
     ap.add_argument("--e2e-reads", type=int, default=96000, help="reads of the synthetic BAM of the end-to-end run (96000 ~ 5 GB: start-up amortised)")
+    ap.add_argument("--e2e-cycles", type=int, default=2, help="how often the end-to-end file may repeat the read pool (4 with --e2e-reads 234000: configs[2] in full)")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
                     help="CNN arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (e.g. front_waves=8)")
@@ -510,7 +511,7 @@ def main():
         out.update(extras)
         if world == 1 and not args.no_extras and not args.no_e2e:
             mc.close()   # the CLI is a process of its own on the same device
-            out["end_to_end"] = end_to_end(slabs, args.e2e_reads, extra_flags=("-Z",))
+            out["end_to_end"] = end_to_end(slabs, args.e2e_reads, extra_flags=("-Z",) if args.e2e_cycles <= 2 else (), cycles=args.e2e_cycles)
         if want_parity and streamed:
             what = (f"(records taken from the STREAMED run of that slab: reads of trunk groups 0, {n_groups // 2} and {n_groups - 1} "
                     f"of its {n_groups} groups per context) ")

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -176,7 +177,7 @@ struct hm_engine {
     // take at most a quarter of it, and at most 16 Mi bases (effective_group_bases).  Two engines on one device, or ranks sharing a
     // GPU, then fit by construction; hm_get_timing reports what was chosen and what is allocated.
     int64_t group_bases = 0;
-    int64_t group_bases_eff = 0;
+    std::atomic<int64_t> group_bases_eff{0};  // staging threads of several batches may ask at once: all compute the same figure
     bool stamps_on = false;
     std::vector<unsigned long long> stamp_sum;
     bool timing = false;
@@ -208,7 +209,7 @@ constexpr int64_t GROUP_BYTES_PER_BASE = (3 * 2 * 512 + 2 * 384 + 768 + 4 + 8) *
 
 int64_t effective_group_bases(hm_engine* e) {
     if (e->group_bases > 0) return e->group_bases;
-    if (e->group_bases_eff > 0) return e->group_bases_eff;
+    if (const int64_t have = e->group_bases_eff.load(std::memory_order_relaxed)) return have;
     size_t free_b = 0, total_b = 0;
     int64_t gb = int64_t(2) << 20;
     if (hipSetDevice(e->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
@@ -216,7 +217,7 @@ int64_t effective_group_bases(hm_engine* e) {
         gb = std::min<int64_t>(gb, int64_t(16) << 20);
         gb = std::max<int64_t>(gb >> 20 << 20, int64_t(1) << 20);  // whole Mi, at least one
     }
-    e->group_bases_eff = gb;
+    e->group_bases_eff.store(gb, std::memory_order_relaxed);
     return gb;
 }
 
