@@ -421,12 +421,15 @@ def main():
             algorithmic = flop_front_sites(served) / (trunk_ms * 1e-3) / 1e12
             # MFMAs per 112-position tile: position tiles of 16 rows x channel tiles x k-blocks (conv1: one stacked product over 6 | 7
             # k-blocks; conv2..conv4: three split-half products over 12 k-blocks).  trunk3 (sliding window): 7 position tiles in every
-            # layer; trunk2: 9 / 9 / 8 / 7 (the halo recomputed per tile).  (Warm-up steps -- one per read and view, < 1 % -- not counted.)
+            # layer; trunk2: 9 / 9 / 8 / 7 (the halo recomputed per tile).
             rows = (7, 7, 7, 7) if trunk_impl == 3 else (9, 9, 8, 7)
             mfma_tile = {c: rows[0] * (6 if c < 2 else 7) * 8 + (rows[1] + rows[2]) * 36 * 8 + rows[3] * 36 * 6 for c in range(3)}
             # tiles whose conv4 ran over the listed (needed) rows only -- counted by the kernel -- issued 4 instead of 7 position tiles there
             listed = list(tm["trunk_list_steps"])
-            n_mfma = sum(tm["trunk_positions"][c] / 112.0 * mfma_tile[c] - listed[c] * 3 * 36 * 6 for c in range(3))
+            # tiles stored as constant rows (a read's first tile, the tiles behind its end: no receptive field reaches the read) issued none;
+            # a workgroup's calibration step and the warm-up step of a run that starts inside a read (< 0.3 %) are not counted
+            const_tiles = list(tm.get("trunk_const_steps", [0, 0, 0]))
+            n_mfma = sum((tm["trunk_positions"][c] / 112.0 - const_tiles[c]) * mfma_tile[c] - listed[c] * 3 * 36 * 6 for c in range(3))
             executed = n_mfma * 16384.0 / (trunk_ms * 1e-3) / 1e12
             kname = ("trunk3_kernel (sliding window over consecutive tiles: every layer computes 112 rows per tile, the right-hand rows kept in LDS)"
                      if trunk_impl == 3 else "trunk2_kernel")
@@ -439,7 +442,7 @@ def main():
                     "executed": executed, "frac_executed": executed / peak, "utilisation": executed / peak,
                     "algorithmic": algorithmic, "algorithmic_over_peak": algorithmic / peak,
                     "algorithmic_flops_per_site": {"CpG": 2 * MAC_FRONT[0], "CHG": 2 * MAC_FRONT[1], "CHH": 2 * MAC_FRONT[2]},
-                    "mfma_per_tile": mfma_tile, "tiles": [tm["trunk_positions"][c] // 112 for c in range(3)], "tiles_conv4_on_listed_rows": listed,
+                    "mfma_per_tile": mfma_tile, "tiles": [tm["trunk_positions"][c] // 112 for c in range(3)], "tiles_conv4_on_listed_rows": listed, "tiles_constant": const_tiles,
                     "positions_per_site": sum(tm["trunk_positions"]) / max(1, sites_job),
                     "sustained_peak_random_operands": 1880.0,
                     "frac_of_sustained": executed / 1880.0,

@@ -36,7 +36,7 @@ class hm_timing_t(C.Structure):
                 ("trunk_ms", C.c_double * 3), ("edge_ms", C.c_double * 3),
                 ("trunk_launches", C.c_int64 * 3), ("edge_launches", C.c_int64 * 3),
                 ("trunk_positions", C.c_int64 * 3),
-                ("trunk_list_steps", C.c_int64 * 3),
+                ("trunk_list_steps", C.c_int64 * 3), ("trunk_const_steps", C.c_int64 * 3),
                 ("group_bases", C.c_int64), ("group_bytes", C.c_int64)]
 
 

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
     const int n_sites = resolve_sites(sr, sites);
     __shared__ __attribute__((aligned(16))) half_t smem[2 * E2_MSET + 2 * E2_SPLANE + E2_XH];
     __shared__ E2Site sinfo2[2][EG_S];
+    __shared__ int32_t rowtab[2][3][E2_MROWS];       // [pass buffer][layer - 2][map-set row] -> row of the layer's map (what a DMA piece gathers)
     half_t* mset = smem;                             // [set][E2_MSET]
     half_t* sp_hi = smem + 2 * E2_MSET;
     half_t* sp_lo = sp_hi + E2_SPLANE;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
     };
     auto desc_b = [&]() __attribute__((always_inline)) { nd.ri = rinfo[nd.st.read_idx]; };
     auto desc_c = [&]() __attribute__((always_inline)) { nd.bs = bases[nd.ri.base_off + nd.st.qoff]; };
-    auto desc_d = [&](const int s0, E2Site* si) __attribute__((always_inline)) {
+    auto desc_d = [&](const int s0, E2Site* si, int32_t (*rt)[E2_MROWS]) __attribute__((always_inline)) {
         if (tid < EG_S) {
             E2Site es;
             es.bo = nd.ri.base_off;
@@ -164,6 +165,14 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
             es.valid = nd.valid;
             si[tid] = es;
             if (es.valid) e4row[s0 + tid] = (int32_t)(es.vrow + es.off - 215);
+        }
+        // map rows of the pass's DMA pieces: thread 96 l + r holds the descriptor of site r & 31 (every thread loaded one)
+        if (tid < 3 * E2_MROWS) {
+            const int l = tid / E2_MROWS, j = (tid - l * E2_MROWS) >> 5;
+            const int view = nd.bs == 2, off = view ? nd.ri.len - 1 - nd.st.qoff : nd.st.qoff;
+            const int r0 = l == 0 ? G::R1 : l == 1 ? G::R2 : G::R3, step = 2 << l;
+            const int delta = j == 0 ? G::LEFT : r0 + (j - 1) * step;
+            (&rt[0][0])[tid] = (int32_t)((int64_t)view * mp.view_rows + nd.ri.map_off + TR_PAD + off + delta);
         }
     };
     // feature rows of conv1's first / last output: K1 rows per pseudo-row, the one on the zero padding all zeros.
@@ -198,27 +207,22 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
     // rows of 33 chunks -- a row's 512 bytes [hi | lo] as they lie in HBM + its pad, which re-reads chunk 31).  `dma_src` reads the
     // site's descriptor, `dma_issue` (a block of the MFMA stream later) forms the address and issues the piece -----------------------
     struct DmaSrc {
-        int64_t vrow;
-        int32_t off;
+        int32_t rn;    // row of the layer's map
+        uint32_t ch;   // 16-byte chunk of that row
     };
-    auto dma_src = [&](auto ltag, const E2Site* si, const int i) __attribute__((always_inline)) {
+    // chunk c of a map set = chunk c % 33 of set row c / 33 (chunk 32 = the pad: chunk 31 again); c < 3 200, so c / 33 = c * 1986 >> 16
+    auto dma_src = [&](auto ltag, const int32_t* rt, const int i) __attribute__((always_inline)) {
         using L = E2L<K1, decltype(ltag)::value>;
-        const int ic = min(i, L::NI - 1);
-        const int row = min((ic * 64 + lane) / 33, L::ROWS - 1);
-        const E2Site* e = si + (row & (EG_S - 1));
-        return DmaSrc{e->vrow, e->off};
+        const uint32_t c = (uint32_t)min(i, L::NI - 1) * 64u + (uint32_t)lane;
+        const uint32_t row = (c * 1986u) >> 16;
+        const uint32_t ch = min(c - 33u * row, 31u);
+        return DmaSrc{rt[min(row, (uint32_t)(L::ROWS - 1))], ch};
     };
     auto dma_issue = [&](auto ltag, const DmaSrc& d, const int set, const int i) __attribute__((always_inline)) {
         using L = E2L<K1, decltype(ltag)::value>;
-        const half_t* __restrict__ map = reinterpret_cast<const half_t*>(mp.e[decltype(ltag)::value - 2]);
+        const char* __restrict__ map = reinterpret_cast<const char*>(mp.e[decltype(ltag)::value - 2]);
         if (i < L::NI) {  // wave-uniform
-            const int c = i * 64 + lane;
-            int row = c / 33;
-            const int ch = min(c - 33 * row, 31);
-            row = min(row, L::ROWS - 1);
-            const int j = row >> 5;
-            const int delta = j == 0 ? G::LEFT : L::R + (j - 1) * L::STEP;
-            const half_t* src = map + (size_t)(d.vrow + d.off + delta) * 256 + ch * 8;
+            const char* src = map + (uint64_t)((uint32_t)d.rn * 32u + d.ch) * 16u;  // (a group's maps have < 2^27 rows: hm_engine.cpp caps group_bases)
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_mset + (uint32_t)((set * E2_MSET) * 2 + i * 1024));
             uint32_t km;
             asm volatile(
@@ -232,11 +236,11 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
         }
     };
     // all pieces of a wave at once (first pass)
-    auto dma_maps = [&](auto ltag, const E2Site* si, const int set, const int w0, auto nw_) __attribute__((always_inline)) {
+    auto dma_maps = [&](auto ltag, const int32_t* rt, const int set, const int w0, auto nw_) __attribute__((always_inline)) {
         using L = E2L<K1, decltype(ltag)::value>;
         constexpr int nw = decltype(nw_)::value;
 #pragma unroll
-        for (int t = 0; t < (L::NI + nw - 1) / nw; ++t) dma_issue(ltag, dma_src(ltag, si, w0 + nw * t), set, w0 + nw * t);
+        for (int t = 0; t < (L::NI + nw - 1) / nw; ++t) dma_issue(ltag, dma_src(ltag, rt, w0 + nw * t), set, w0 + nw * t);
     };
     using L2t = std::integral_constant<int, 2>;
     using L3t = std::integral_constant<int, 3>;
@@ -251,9 +255,10 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
         float4 bz;
     };
     auto load_head1 = [&](Head1& h) __attribute__((always_inline)) {
-        const half8* wp = reinterpret_cast<const half8*>(W.c1f) + (size_t)wave * KB1 * 64 + lane;
+        const char* wp = reinterpret_cast<const char*>(W.c1f) + (size_t)wave * (KB1 * 1024);
+        const uint32_t lo = (uint32_t)lane * 16u;
 #pragma unroll
-        for (int kb = 0; kb < KB1; ++kb) h.w[kb] = wp[kb * 64];
+        for (int kb = 0; kb < KB1; ++kb) h.w[kb] = *reinterpret_cast<const half8*>(wp + kb * 1024 + lo);
         const int col = wave * 16 + 4 * lk;
         h.bz = *reinterpret_cast<const float4*>(W.c1f_bias + col);
     };
@@ -297,16 +302,18 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
         half8 w[12][2];
         float4 bz;
     };
+    // (uniform base + this lane's 32-bit byte offset: the loads take the scalar-base form, no 64-bit address arithmetic per load)
     auto wptr = [&](auto ltag) __attribute__((always_inline)) {
         constexpr int LAYER = decltype(ltag)::value;
         const int nt = LAYER == 4 ? min(wave, C4_CH / 16 - 1) : wave;
-        return reinterpret_cast<const half8*>(wf(LAYER - 1)) + (size_t)nt * 12 * 128 + lane;
+        return reinterpret_cast<const char*>(wf(LAYER - 1)) + (size_t)nt * (12 * 128 * 16);
     };
     auto load_kb = [&](auto ltag, auto kb_, LW& lw) __attribute__((always_inline)) {
         constexpr int LAYER = decltype(ltag)::value, kb = decltype(kb_)::value;
-        const half8* wp = wptr(ltag);
-        lw.w[kb][0] = wp[kb * 128];
-        lw.w[kb][1] = wp[kb * 128 + 64];
+        const char* wp = wptr(ltag) + kb * 2048;
+        const uint32_t lo = (uint32_t)lane * 16u;
+        lw.w[kb][0] = *reinterpret_cast<const half8*>(wp + lo);
+        lw.w[kb][1] = *reinterpret_cast<const half8*>(wp + 1024 + lo);
         if constexpr (kb == 0) lw.bz = *reinterpret_cast<const float4*>(W.bias[LAYER - 1] + (LAYER == 4 ? min(wave, C4_CH / 16 - 1) : wave) * 16 + 4 * lk);
     };
     // one layer on this wave's n-tile.  `slide(kb)` is called when the registers of k-block kb - E2_AHEAD are free: the caller
@@ -385,12 +392,12 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
         desc_a(s0);
         desc_b();
         desc_c();
-        desc_d(s0, sinfo2[0]);
+        desc_d(s0, sinfo2[0], rowtab[0]);
         load_head1(h1);
         __syncthreads();
         build_rows(sinfo2[0], tid, std::integral_constant<int, NW * 64>{}, [] {});
         e2_vmwait<0>();
-        dma_maps(L2t{}, sinfo2[0], 0, wave, NW8{});
+        dma_maps(L2t{}, rowtab[0][0], 0, wave, NW8{});
         e2_vmwait<0>();
     }
     int cur = 0, sel = 0;
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
                       constexpr int b = decltype(b_)::value, NP = (E2L<K1, 3>::NI + NW - 1) / NW;
                       static_assert(NP < E2L<K1, 2>::NB, "the pieces fit the layer's blocks");
                       if constexpr (b >= 1 && b - 1 < NP) dma_issue(L3t{}, ds, sel ^ 1, wave + NW * (b - 1));
-                      if constexpr (b < NP) ds = dma_src(L3t{}, sinfo2[cur], wave + NW * b);
+                      if constexpr (b < NP) ds = dma_src(L3t{}, rowtab[cur][1], wave + NW * b);
                   });
             ETS(3);
             e2_vmwait<0>();
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
                       constexpr int b = decltype(b_)::value, NP = (E2L<K1, 4>::NI + NW - 1) / NW;
                       static_assert(NP < E2L<K1, 3>::NB, "the pieces fit the layer's blocks");
                       if constexpr (b >= 1 && b - 1 < NP) dma_issue(L4t{}, ds, sel, wave + NW * (b - 1));
-                      if constexpr (b < NP) ds = dma_src(L4t{}, sinfo2[cur], wave + NW * b);
+                      if constexpr (b < NP) ds = dma_src(L4t{}, rowtab[cur][2], wave + NW * b);
                   });
             ETS(6);
             e2_vmwait<0>();
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
             const EpiSpec epi{sp_hi, sp_lo, nullptr};
 #pragma unroll
             for (int i = 0; i < 4; ++i) epi(i * 16 + li, wave * 16 + 4 * lk, acc[i]);
-            desc_d(sn, sinfo2[cur ^ 1]);
+            desc_d(sn, sinfo2[cur ^ 1], rowtab[cur ^ 1]);
             lw = ln;
         }
         e2_barrier();
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(512) void edge2_kernel(SiteRange sr, const RInfo* _
                 constexpr int b = decltype(b_)::value, NP = (E2L<K1, 2>::NI + NWC - 1) / NWC;
                 static_assert(NP < E2L<K1, 4>::NB, "the pieces fit the layer's blocks");
                 if constexpr (b >= 1 && b - 1 < NP) dma_issue(L2t{}, ds, sel ^ 1, wave + NWC * (b - 1));
-                if constexpr (b < NP) ds = dma_src(L2t{}, si_next, wave + NWC * b);
+                if constexpr (b < NP) ds = dma_src(L2t{}, rowtab[cur ^ 1][0], wave + NWC * b);
             });
             const EpiEdgeOut epi{reinterpret_cast<half_t*>(edge4) + (size_t)s0 * (4 * C4_CH), nullptr, nvalid};
 #pragma unroll

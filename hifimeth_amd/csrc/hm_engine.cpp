@@ -133,10 +133,10 @@ struct hm_batch {
     // device
     DevBuf d_raw, d_reads, d_chunks, d_rinfo, d_tiles, d_bases, d_kin, d_sctx, d_counts, d_offs, d_totals, d_err;
     DevBuf d_usites, d_utag, d_csites, d_opos, d_logits, d_p, d_ml, d_calls;
-    int32_t* h_totals = nullptr;  // pinned [12]: the scan kernel's 8 totals + [8..10] the trunk's listed-row steps per context
+    int32_t* h_totals = nullptr;  // pinned [16]: the scan kernel's 8 totals + the trunk's [8..10] listed-row and [12..14] constant steps per context
     int32_t* h_err = nullptr;     // pinned
     PinnedArr<hm_call_t> h_calls;
-    int32_t totals[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t totals[16] = {};
 
     std::vector<TimedSpan> spans;
 };
@@ -278,6 +278,7 @@ void collect_timing(hm_engine* e, std::vector<TimedSpan>& spans, const int32_t* 
     if (!spans.empty() && totals) {  // once per timed run of a batch
         std::lock_guard<std::mutex> lk(e->mu);
         for (int c = 0; c < 3; ++c) e->acc.trunk_list_steps[c] += totals[8 + c];
+        for (int c = 0; c < 3; ++c) e->acc.trunk_const_steps[c] += totals[12 + c];
     }
     for (auto& s : spans) {
         float ms = 0.f;
@@ -402,14 +403,14 @@ hm_batch* new_slot(hm_engine* e, int id) {
     HIP_TRY(hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&b->ev_comp, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&b->ev_out, hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 12 * sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_totals), 16 * sizeof(int32_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_err), sizeof(int32_t), hipHostMallocDefault));
-    memset(b->h_totals, 0, 12 * sizeof(int32_t));
+    memset(b->h_totals, 0, 16 * sizeof(int32_t));
     *b->h_err = 0;
-    b->d_totals.reserve(12 * sizeof(int32_t));
+    b->d_totals.reserve(16 * sizeof(int32_t));
     b->d_err.reserve(sizeof(int32_t));
     HIP_TRY(hipMemset(b->d_err.p, 0, sizeof(int32_t)));
-    HIP_TRY(hipMemset(b->d_totals.p, 0, 12 * sizeof(int32_t)));
+    HIP_TRY(hipMemset(b->d_totals.p, 0, 16 * sizeof(int32_t)));
     hm_batch* raw = b.get();
     e->slots.push_back(std::move(b));
     return raw;
@@ -554,7 +555,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
     for (int i = 0; i < 3; ++i) e->d_map[i].reserve((size_t)max_rows * 2 * 256 * sizeof(uint16_t));
     e->d_e4.reserve((size_t)max_rows * 2 * C4_CH * sizeof(float));
     e->d_rowlist.reserve(std::max((size_t)(max_rows / TR_OWN + 1) * 2 * 3 * TR_OWN, trunk3_rowlist_bytes((max_rows / TR_OWN + 1) * 2)));
-    e->d_dump.reserve(trunk3_dump_bytes());
+    e->d_dump.reserve(trunk3_dump_bytes(e->num_cu));
     e->d_edge4.reserve((size_t)max_bases * 2 * C4_CH * sizeof(float));
     e->d_e4row.reserve((size_t)max_bases * sizeof(int32_t));
     if (!e->d_zeros.p) {
@@ -759,7 +760,7 @@ void enqueue_run(hm_batch* b) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev_comp, e->stream));
     HIP_TRY(hipStreamWaitEvent(b->s_io, b->ev_comp, 0));
-    HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals.p, 12 * sizeof(int32_t), hipMemcpyDeviceToHost, b->s_io));
+    HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals.p, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, b->s_io));
     HIP_TRY(hipMemcpyAsync(b->h_err, b->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, b->s_io));
     HIP_TRY(hipEventRecord(b->ev_out, b->s_io));
     b->ran = true;
@@ -919,7 +920,8 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
         if (value < 16) return fail(e, HM_EINVAL, "tail_slice must be at least 16");
         e->tail_slice = value;
     } else if (k == "group_bases") {
-        if (value < 0) return fail(e, HM_EINVAL, "group_bases must be positive (0: sized from free device memory)");
+        if (value < 0 || value > (int64_t(48) << 20))  // (48 Mi bases = 190 GB of maps; the edge kernel counts map rows in 27 bits)
+            return fail(e, HM_EINVAL, "group_bases must be 1 .. 48 Mi (0: sized from free device memory)");
         e->group_bases = value;
     } else if (k == "slots") {
         if (value < 1 || value > 16) return fail(e, HM_EINVAL, "slots must be 1..16");

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const int32_t* __res
         totals[5] = t0;
         totals[6] = t0 + t1;
         totals[7] = part[4][threadIdx.x];  // reverse-strand sites
-        totals[8] = totals[9] = totals[10] = totals[11] = 0;  // per context: trunk steps whose conv4 ran over listed rows only (hm_trunk3.hip)
+        for (int i = 8; i < 16; ++i) totals[i] = 0;  // per context: [8..10] trunk steps whose conv4 ran over listed rows only, [12..14] constant steps (hm_trunk3.hip)
     }
 }
 

@@ -21,6 +21,14 @@
 // edge chains do read E1 .. E3 at positions -199 .. -173 of a read: those rows are new rows of the read's warm-up step).
 // Same products in the same order per accumulator as trunk2_kernel: byte-identical maps (tests/test_gpu_parity.py).
 //
+// CONSTANT steps.  E1[x] .. E4[x] see the feature rows x .. x + 12 / 16 / 24 / 40: where none of them lies inside the read (all
+// feature rows zero) every layer's row is ONE row that depends on nothing but the weights.  That holds for all new rows of a step at
+// u <= -152 (a read's warm-up step and its first tile) and at u >= len (the tiles behind the read's end): 3 - 4 of a read's ~ 142 steps.
+// A workgroup therefore starts with a CALIBRATION step -- an ordinary step on all-zero feature rows whose stores go to a scratch
+// buffer -- keeps the four constant rows it produces (its kept rows ARE E1's .. E3's, its last conv4 row E4's: same instructions,
+// same bytes as a computed step's), and a constant step only stores: the E4 rows of the tile, the E1 .. E3 rows the lists flag, and
+// the constants as the kept rows of the step behind it.  No warm-up step is computed at a read's start any more.
+//
 // Reference for what is computed: training/model_cnn.py:8-85 / models/*.onnx (mod_main.cpp:32-98).
 #include "hm_convh.h"
 #ifdef HM_TRUNK_STAMP  // diagnostic build (make stamp): per-wave shader-clock phase sums of workgroup 0, read by tools/trunk3_stamps.py
@@ -218,7 +226,9 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     static_assert(sizeof(smem) == 147840, "LDS plan");
     __shared__ uint32_t rlist[2][T3_RLW];  // the step's record ([3][128] bytes of row lists, the E4 list, its count); two buffers: conv4 still reads one while the next step's arrives
     __shared__ int64_t s_grow0;
-    __shared__ int s_warm;
+    __shared__ int s_kind;   // bit 0: warm-up step (E4 rows to the dump), bit 1: constant step, bit 2: the calibration step
+    __shared__ __attribute__((aligned(16))) half_t kc[3][2][128];   // E1's, E2's, E3's constant row: [layer][hi | lo][channel]
+    __shared__ __attribute__((aligned(16))) half_t e4c[2 * C4_CH];  // E4's, as a map row [hi 96 | lo 96]
     half_t* a_hi = smem;
     half_t* a_lo = a_hi + T3_AROWS * TR_RS;
     half_t* b_hi = a_lo + T3_AROWS * TR_RS;
@@ -245,7 +255,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     struct Build {
         TrunkTile tl;
         RInfo ri;
-        int w, view, warm, ueff, b;
+        int w, view, warm, cst, calib, ueff, b;
         uint32_t k, rl;
     } bd;
     auto build_desc1 = [&](const int w) __attribute__((always_inline)) {
@@ -258,6 +268,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         bd.tl.read_idx = __builtin_amdgcn_readfirstlane(bd.tl.read_idx);
         bd.tl.u0 = __builtin_amdgcn_readfirstlane(bd.tl.u0);
         bd.warm = first ? 1 : (prev_warm ? 0 : (bd.tl.u0 == -TR_PAD));
+        bd.calib = 0;
         bd.ueff = bd.tl.u0 - (bd.warm ? TR_OWN : 0);
         bd.ri = rinfo[bd.tl.read_idx];
     };
@@ -266,6 +277,8 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         bd.ri.map_off = __builtin_amdgcn_readfirstlane(bd.ri.map_off);
         bd.ri.base_off = ((int64_t)__builtin_amdgcn_readfirstlane((int)(bd.ri.base_off >> 32)) << 32) |
                          (uint32_t)__builtin_amdgcn_readfirstlane((int)bd.ri.base_off);
+        // nothing of the read in any new row's receptive field: a read's warm-up step and first tile, the tiles behind its end
+        bd.cst = bd.tl.u0 == -TR_PAD || (!bd.warm && bd.tl.u0 >= bd.ri.len);
     };
     auto build_loads = [&]() __attribute__((always_inline)) {
         const int r = threadIdx.x, L = bd.ri.len, x = bd.ueff + T3_S1 + r;
@@ -274,17 +287,17 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         bd.b = bases[j];
         bd.k = kin[j];
         // the step's lists: the tile's own; a read's warm-up step's; the all-fill list of a warm-up step in the middle of a read
-        const size_t li = bd.warm ? (bd.tl.u0 == -TR_PAD ? (size_t)n_work + bd.w : (size_t)2 * n_work) : (size_t)bd.w;
+        const size_t li = bd.calib ? (size_t)2 * n_work : bd.warm ? (bd.tl.u0 == -TR_PAD ? (size_t)n_work + bd.w : (size_t)2 * n_work) : (size_t)bd.w;
         bd.rl = reinterpret_cast<const uint32_t*>(mp.rowlist + li * T3_RL)[min(r, T3_RL / 4 - 1)];
     };
     auto build_store = [&](const int buf) __attribute__((always_inline)) {
         const int r = threadIdx.x, x = bd.ueff + T3_S1 + r;
         if (r == 0) {
             s_grow0 = (int64_t)bd.view * mp.view_rows + bd.ri.map_off + (bd.ueff + TR_PAD);
-            s_warm = bd.warm;
+            s_kind = bd.warm | (bd.cst << 1) | (bd.calib << 2);
         }
         if (r < T3_XROWS) {
-            const bool in = x >= 0 && x < bd.ri.len;
+            const bool in = !bd.calib && x >= 0 && x < bd.ri.len;
             *reinterpret_cast<uint4*>(xb + r * TR_WRS) = feature_row(in ? bd.b : -1, bd.k, bd.view);
         }
         if (r < T3_RL3 / 4) rlist[buf][r / (TR_OWN / 4) * 32 + r % (TR_OWN / 4)] = bd.rl;
@@ -313,11 +326,20 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     build_desc1(w0);
     build_desc2(0, true);
     build_desc3();
+    bd.calib = 1;          // the first step: calibration (all feature rows zero, every store into the scratch buffer)
+    bd.cst = 0;
     build_loads();
     build_store(0);
     int buf = 0;
     int w = w0, warm = 1;  // the step being computed
     int n_list = 0;        // steps of this workgroup whose conv4 ran over the listed rows only
+    int n_const = 0;       // tiles that were constant steps
+    bool prev_calib = false;
+    // scratch (engine: trunk3_dump_bytes): [0] a warm-up step's E4 rows (garbage), [1] the copy slots of the calibration step (128 map
+    // rows), then per workgroup the calibration step's E4 rows (the last one is E4's constant row)
+    half_t* const dump_rows = dump + TR_OWN * 2 * C4_CH;
+    half_t* const dump_cal = dump_rows + 128 * 256 + (size_t)blockIdx.x * (TR_OWN * 2 * C4_CH);
+    constexpr int first_new[3] = {T3_H1, T3_H2, T3_H3};
 #ifdef HM_TRUNK_STAMP
     // per layer: [0] barrier -> run returns, [3] wait at the next barrier; slot 22 / 23: s_memtime / s_memrealtime of the whole loop
     unsigned long long ts[10], acc_t[16] = {};
@@ -332,15 +354,77 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         __syncthreads();  // the step's feature rows, lists and descriptors are in LDS; the previous step is through with the planes
         TS(0);
         const int64_t grow0 = s_grow0;
-        const int cur_warm = __builtin_amdgcn_readfirstlane(s_warm);
+        const int kind = __builtin_amdgcn_readfirstlane(s_kind);
+        const int cur_warm = kind & 1, cur_const = (kind >> 1) & 1, cur_calib = kind >> 2;
+        if (prev_calib) {
+            // the calibration step is through: its kept rows are the constant rows of E1 .. E3, its last conv4 row (scratch) is E4's
+            prev_calib = false;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int t = threadIdx.x;
+            if (t < 96) {
+                const int l = t >> 5, plane = (t >> 4) & 1, col = (t & 15) * 8;
+                const half_t* src = l == 0 ? (plane ? h1_lo : h1_hi) : l == 1 ? (plane ? b_lo : b_hi) : (plane ? h3_lo : h3_hi);
+                *reinterpret_cast<uint4*>(&kc[l][plane][col]) = *reinterpret_cast<const uint4*>(src + col);
+            } else if (t < 96 + 24) {
+                reinterpret_cast<uint4*>(e4c)[t - 96] = reinterpret_cast<const uint4*>(dump_cal + (TR_OWN - 1) * 2 * C4_CH)[t - 96];
+            }
+            __syncthreads();
+        }
         // the next step
         const int wn = cur_warm ? w : w + 1;
         const bool last = wn >= w1;
         // (a read's warm-up step starts 112 rows in front of the read's region: these bases may lie in front of it -- only rows inside are stored)
-        half_t* g1 = reinterpret_cast<half_t*>(mp.e[0]) + (grow0 + T3_S2) * 256;   // plane A row 0 as E1 = position u + 24
-        half_t* g2 = reinterpret_cast<half_t*>(mp.e[1]) + (grow0 + T3_S3) * 256;   // plane B row 0 = position u + 16
-        half_t* g3 = reinterpret_cast<half_t*>(mp.e[2]) + grow0 * 256;             // plane A row 0 as E3 = position u
+        half_t* g1 = cur_calib ? dump_rows : reinterpret_cast<half_t*>(mp.e[0]) + (grow0 + T3_S2) * 256;   // plane A row 0 as E1 = position u + 24
+        half_t* g2 = cur_calib ? dump_rows : reinterpret_cast<half_t*>(mp.e[1]) + (grow0 + T3_S3) * 256;   // plane B row 0 = position u + 16
+        half_t* g3 = cur_calib ? dump_rows : reinterpret_cast<half_t*>(mp.e[2]) + grow0 * 256;             // plane A row 0 as E3 = position u
         const uint8_t* rl = reinterpret_cast<const uint8_t*>(rlist[buf]);
+        if (cur_const) {
+            // ---- a constant step: nothing to compute.  Its stores first: they drain while the next step's descriptors (three dependent
+            // loads, this step's length) arrive ----
+            const int t = threadIdx.x;
+            n_const += !cur_warm;  // (tiles: a read's warm-up step is no tile)
+            if (!cur_warm) {  // the tile's E4 rows (a read's warm-up step lies in front of its region)
+                uint4* g4 = reinterpret_cast<uint4*>(reinterpret_cast<half_t*>(mp.e4) + grow0 * (2 * C4_CH));
+                const uint4 v = reinterpret_cast<const uint4*>(e4c)[t % 24];   // (256 = 16 mod 24: a thread's chunk column moves by 16 per round)
+                const uint4 v2 = reinterpret_cast<const uint4*>(e4c)[(t + 16) % 24], v3 = reinterpret_cast<const uint4*>(e4c)[(t + 8) % 24];
+#pragma unroll
+                for (int k = 0; k < (TR_OWN * 24 + 255) / 256; ++k) {
+                    const int c = t + 256 * k;
+                    if (c < TR_OWN * 24) g4[c] = k % 3 == 0 ? v : k % 3 == 1 ? v2 : v3;
+                }
+            }
+            // the E1 .. E3 rows the lists flag (the fill entries -- the last new row -- once)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const uint8_t* rows = rl + 128 * l;
+                half_t* g = l == 0 ? g1 : l == 1 ? g2 : g3;
+                const int fill = first_new[l] + TR_OWN - 1, ch = t & 31;
+                const uint4 v = reinterpret_cast<const uint4*>(&kc[l][0][0])[ch];
+                for (int e = t >> 5; e < TR_OWN; e += 8) {
+                    const int p = rows[e];
+                    if (p != fill) reinterpret_cast<uint4*>(g + (size_t)p * 256)[ch] = v;
+                }
+                if (t < 32) reinterpret_cast<uint4*>(g + (size_t)fill * 256)[ch] = v;  // (the last new row may be flagged itself)
+            }
+            // the kept rows of the step behind this one: 4 + 8 + 16 rows of constants
+            for (int c = t; c < (T3_H1 + T3_H2 + T3_H3) * 32; c += NW * 64) {
+                const int row = c >> 5, plane = (c >> 4) & 1, col = (c & 15) * 8;
+                const int l = row < T3_H1 ? 0 : row < T3_H1 + T3_H2 ? 1 : 2, r = row - (l == 0 ? 0 : l == 1 ? T3_H1 : T3_H1 + T3_H2);
+                half_t* dst = (l == 0 ? (plane ? h1_lo : h1_hi) : l == 1 ? (plane ? b_lo : b_hi) : (plane ? h3_lo : h3_hi)) + r * TR_RS + col;
+                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&kc[l][plane][col]);
+            }
+            build_desc1(min(wn, w1 - 1));
+            build_desc2(cur_warm, false);
+            build_desc3();
+            build_loads();
+            __syncthreads();  // every wave has read this step's record and kind
+            build_store(buf ^ 1);
+            buf ^= 1;
+            if (last) break;
+            w = wn;
+            warm = bd.warm;
+            continue;
+        }
         // E1's kept rows come back into plane A (conv4 of the previous step is through with its rows 0 .. 3)
         move_rows<T3_H1, NW * 64>(a_hi, a_lo, h1_hi, h1_lo, threadIdx.x);
         L1::run(xb, xb, wr, EpiTrunk3{a_hi + T3_H1 * TR_RS, a_lo + T3_H1 * TR_RS}, wf(1), W.bias[1], nt0, nt0);
@@ -348,7 +432,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         TS(1);
         __syncthreads();
         TS(2);
-        build_desc2(cur_warm, false);
+        build_desc2(cur_warm, cur_calib != 0);
         L2::run(a_hi, a_lo, wr, EpiTrunk3{b_hi + T3_H2 * TR_RS, b_lo + T3_H2 * TR_RS}, wf(2), W.bias[2], nt0, nt0, CopyRows3<NW>{rl, g1});
         // E1's last rows wait in H1 for the next step (conv3 is about to overwrite them)
         move_rows<T3_H1, NW * 64>(h1_hi, h1_lo, a_hi + T3_M * TR_RS, a_lo + T3_M * TR_RS, threadIdx.x);
@@ -367,7 +451,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         move_rows<T3_H3, NW * 64>(h3_hi, h3_lo, a_hi + T3_M * TR_RS, a_lo + T3_M * TR_RS, threadIdx.x);
         move_rows<T3_H2, NW * 64>(b_hi, b_lo, b_hi + T3_M * TR_RS, b_lo + T3_M * TR_RS, threadIdx.x);
         // a warm-up step's E4 rows are not results (its kept rows were not): they go to the dump
-        const EpiE43 e4{cur_warm ? dump : reinterpret_cast<half_t*>(mp.e4) + grow0 * (2 * C4_CH)};
+        const EpiE43 e4{cur_calib ? dump_cal : cur_warm ? dump : reinterpret_cast<half_t*>(mp.e4) + grow0 * (2 * C4_CH)};
         const int n4 = __builtin_amdgcn_readfirstlane((int)rlist[buf][T3_RLW - 1]);
         if (!cur_warm && n4 <= T3_N4) {
             ++n_list;
@@ -395,6 +479,10 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         }
         build_store(buf ^ 1);
         buf ^= 1;
+        if (cur_calib) {  // its conv4 rows are read back at the top of the next step
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            prev_calib = true;
+        }
         TS(7);
 #ifdef HM_TRUNK_STAMP
         if (st_on) {
@@ -422,10 +510,11 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
 #endif
 #undef TS
     if (list_steps && threadIdx.x == 0 && n_list) atomicAdd(list_steps + ctx, n_list);
+    if (list_steps && threadIdx.x == 0 && n_const) atomicAdd(list_steps + 4 + ctx, n_const);
 }
 
 size_t trunk3_rowlist_bytes(int64_t n_work) { return (size_t)(2 * n_work + 1) * T3_RL + 64; }
-size_t trunk3_dump_bytes() { return (size_t)TR_OWN * 2 * C4_CH * sizeof(uint16_t); }
+size_t trunk3_dump_bytes(int grid) { return ((size_t)(1 + grid) * TR_OWN * 2 * C4_CH + 128 * 256) * sizeof(uint16_t); }
 
 void launch_trunk3(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w, const TrunkMaps& maps,

@@ -78,6 +78,7 @@ typedef struct {
     int64_t trunk_launches[3], edge_launches[3];
     int64_t trunk_positions[3]; /* (read, strand view) positions evaluated by the timed trunk launches */
     int64_t trunk_list_steps[3]; /* tiles whose conv4 ran over the listed (needed) rows only: 4 m-tiles instead of 7 (sliding-window trunk) */
+    int64_t trunk_const_steps[3]; /* tiles stored as constant rows instead of computed: a read's first tile and those behind its end, where no receptive field reaches the read */
     int64_t group_bases;        /* bases per trunk read group in force (option "group_bases", or what the engine sized from free memory) */
     int64_t group_bytes;        /* device bytes the engine holds for a read group's maps, edge rows and hand-off buffers */
 } hm_timing_t;

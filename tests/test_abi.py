@@ -34,7 +34,7 @@ def test_struct_layout_matches_header():
 
 
 def test_timing_struct_matches_header(tmp_path):
-    """hm_timing_t grows round by round (round 4: trunk_list_steps, group_bases, group_bytes): the ctypes mirror must keep the header's size
+    """hm_timing_t grows round by round (round 4: trunk_list_steps, trunk_const_steps, group_bases, group_bytes): the ctypes mirror must keep the header's size
     and the offsets of its last fields -- checked against what the C compiler makes of include/hifimeth_hip.h."""
     import subprocess
     from hifimeth_amd import _lib

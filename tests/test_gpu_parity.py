@@ -565,7 +565,7 @@ def test_streaming_trunk_is_byte_identical_to_the_8_wave_form():
 @pytest.mark.gpu
 def test_sliding_window_trunk_is_byte_identical_whatever_the_runs_of_tiles():
     """trunk_impl = 3 (hm_trunk3.hip): a workgroup walks a contiguous run of tiles and keeps every layer's right-hand rows for the next
-    tile; kept rows are rebuilt by a warm-up step at the start of a run and of a read.  Where the runs are cut depends on the number
+    tile; kept rows are rebuilt by a warm-up step at the start of a run (at a read's start they are the constant rows).  Where the runs are cut depends on the number
     of workgroups (num_cu) and on the read groups: 1, 3, 7, 256 workgroups and many small groups -- runs that start in the middle of
     a read, runs of a single tile, reads of a single tile, more workgroups than tiles -- all give the streaming trunk's calls byte for
     byte, second batches through the same engine included."""
@@ -588,6 +588,38 @@ def test_sliding_window_trunk_is_byte_identical_whatever_the_runs_of_tiles():
             c = m.call(reads).copy()
         assert a.tobytes() == ref.tobytes() == c.tobytes(), (num_cu, group_bases)
         assert len(b) == len(ref)
+
+
+@pytest.mark.gpu
+def test_constant_steps_store_what_a_computed_step_would():
+    """hm_trunk3.hip, constant steps: a read's warm-up step, its first tile (u = -200) and the tiles behind its end (u >= len) lie where
+    no receptive field reaches the read; the kernel stores the constant rows of a calibration step there instead of computing them.
+    The calls stay byte-identical to the streaming trunk's (every position computed) -- with sites in the first 27 and the last
+    positions of a read (homopolymers: their edge chains read E1 .. E3 rows of the warm-up step and of the tiles behind the end), reads
+    of a few tiles, one workgroup and many -- and the kernel's own count of constant tiles is the one the tile plan gives:
+    per read and strand view the first tile + the tiles at u >= len."""
+    from hifimeth_amd import MethylationCaller
+    reads = _mixed_reads() + synth_reads(7, seed=93, median_len=3000, sigma=0.6, frac_wide=0.3, frac_short=0, frac_missing=0)
+    with MethylationCaller(device=0) as m:
+        m.set_option("trunk", 1)
+        m.set_option("trunk_impl", 1)
+        ref = m.call(reads).copy()
+    want = 0
+    for rd in reads:
+        L = rd.l_qseq
+        ntile = (L + 400 + 111) // 112
+        want += 1 + sum(1 for t in range(ntile) if -200 + 112 * t >= L)
+    for num_cu in (1, 5, 256):
+        with MethylationCaller(device=0, timing=True) as m:
+            m.set_option("trunk", 1)
+            m.set_option("trunk_impl", 3)
+            m.set_option("num_cu", num_cu)
+            got = m.call(reads).copy()
+            tm = m.timing()
+        assert got.tobytes() == ref.tobytes(), num_cu
+        assert list(tm["trunk_const_steps"]) == [want, want, 2 * want], (num_cu, tm["trunk_const_steps"], want)
+        tiles = [p // 112 for p in tm["trunk_positions"]]
+        assert all(0 < c < t // 4 for c, t in zip(tm["trunk_const_steps"], tiles))
 
 
 def test_edge2_is_byte_identical_to_the_staging_edge_kernel():

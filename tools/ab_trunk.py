@@ -26,7 +26,8 @@ for rep in range(3):
             mc.run()
         mc.sync()
         tm = mc.timing()
-        print(f"impl {impl}: trunk {sum(tm['trunk_ms']) / 3:8.2f} ms  edge {sum(tm['edge_ms']) / 3:7.2f}  tail {sum(tm['tail_ms']) / 3:7.2f}   sites {mc.num_sites(3)}", flush=True)
+        print(f"impl {impl}: trunk {sum(tm['trunk_ms']) / 3:8.2f} ms  edge {sum(tm['edge_ms']) / 3:7.2f}  tail {sum(tm['tail_ms']) / 3:7.2f}   sites {mc.num_sites(3)}"
+              f"  steps: all {[x // 336 for x in tm['trunk_positions']]} listed {[x // 3 for x in tm['trunk_list_steps']]} constant {[x // 3 for x in tm.get('trunk_const_steps', [0, 0, 0])]}", flush=True)
 ok = True
 for impl in IMPLS[1:]:
     a, b = out[IMPLS[0]], out[impl]
