@@ -123,15 +123,17 @@ struct hm_batch {
     PinnedArr<Chunk> chunks;
     PinnedArr<RInfo> rinfo;      // dense trunk: per read
     PinnedArr<TrunkTile> tiles;  // dense trunk: 112-position tiles of every read, in read order
+    PinnedArr<int32_t> tcost;    // per group: running cost of its tiles (n_tiles + 1 entries from 0): what the sliding-window trunk cuts its runs by
     struct Group {               // consecutive reads whose maps share one set of buffers
         int chunk_lo, chunk_hi, tile_lo, tile_hi;
         int64_t bases, rows;
+        int cost_lo;             // where the group's running costs start in tcost
     };
     std::vector<Group> groups;
     int64_t total_bases = 0;  // padded to a multiple of 4 per read
 
     // device
-    DevBuf d_raw, d_reads, d_chunks, d_rinfo, d_tiles, d_bases, d_kin, d_sctx, d_counts, d_offs, d_totals, d_err;
+    DevBuf d_raw, d_reads, d_chunks, d_rinfo, d_tiles, d_tcost, d_bases, d_kin, d_sctx, d_counts, d_offs, d_totals, d_err;
     DevBuf d_usites, d_utag, d_csites, d_opos, d_logits, d_p, d_ml, d_calls;
     int32_t* h_totals = nullptr;  // pinned [16]: the scan kernel's 8 totals + the trunk's [8..10] listed-row and [12..14] constant steps per context
     int32_t* h_err = nullptr;     // pinned
@@ -219,6 +221,30 @@ int64_t effective_group_bases(hm_engine* e) {
     }
     e->group_bases_eff.store(gb, std::memory_order_relaxed);
     return gb;
+}
+
+// dense trunk bookkeeping of one staged read: its group (a new one when the current holds group_bases), map region, tiles, and the tiles'
+// running cost -- a tile where no receptive field reaches the read (the first, u = -200, with the read's warm-up step; those at
+// u >= len) is a constant step of trunk3_kernel, an eighth or so of a computed one: the kernel cuts its runs at equal cost
+constexpr int TILE_COST = 8, TILE_COST_CONST = 1;
+void add_read_tiles(hm_engine* e, hm_batch* b, int ridx, int l_qseq) {
+    if (b->groups.empty() || b->groups.back().bases >= effective_group_bases(e)) {
+        b->groups.push_back(hm_batch::Group{(int)b->chunks.n, (int)b->chunks.n, (int)b->tiles.n, (int)b->tiles.n, 0, 0, (int)b->tcost.n});
+        b->tcost.push_back(0);
+    }
+    hm_batch::Group& g = b->groups.back();
+    const int ntile = (l_qseq + 2 * TR_PAD + TR_OWN - 1) / TR_OWN;
+    b->rinfo.push_back(RInfo{b->total_bases, l_qseq, (int32_t)g.rows});
+    for (int t = 0; t < ntile; ++t) {
+        const int u0 = -TR_PAD + t * TR_OWN;
+        b->tiles.push_back(TrunkTile{ridx, u0});
+        b->tcost.push_back(b->tcost.p[b->tcost.n - 1] + (t == 0 ? 2 * TILE_COST_CONST : u0 >= l_qseq ? TILE_COST_CONST : TILE_COST));
+    }
+    for (int st = 0; st < l_qseq; st += CHUNK) b->chunks.push_back(Chunk{ridx, st});
+    g.rows += (int64_t)ntile * TR_OWN + TR_SLACK;
+    g.bases += l_qseq;
+    g.chunk_hi = (int)b->chunks.n;
+    g.tile_hi = (int)b->tiles.n;
 }
 
 int fail(hm_engine* e, int code, const std::string& msg) {
@@ -418,7 +444,7 @@ hm_batch* new_slot(hm_engine* e, int id) {
 
 void free_slot(hm_batch* b) {
     if (b->s_io) (void)hipStreamSynchronize(b->s_io);
-    for (DevBuf* d : {&b->d_raw, &b->d_reads, &b->d_chunks, &b->d_rinfo, &b->d_tiles, &b->d_bases, &b->d_kin, &b->d_sctx, &b->d_counts, &b->d_offs,
+    for (DevBuf* d : {&b->d_raw, &b->d_reads, &b->d_chunks, &b->d_rinfo, &b->d_tiles, &b->d_tcost, &b->d_bases, &b->d_kin, &b->d_sctx, &b->d_counts, &b->d_offs,
                       &b->d_totals, &b->d_err, &b->d_usites, &b->d_utag, &b->d_csites, &b->d_opos, &b->d_logits, &b->d_p,
                       &b->d_ml, &b->d_calls})
         d->release();
@@ -427,6 +453,7 @@ void free_slot(hm_batch* b) {
     b->chunks.release();
     b->rinfo.release();
     b->tiles.release();
+    b->tcost.release();
     b->h_calls.release();
     if (b->h_totals) (void)hipHostFree(b->h_totals);
     if (b->h_err) (void)hipHostFree(b->h_err);
@@ -445,6 +472,7 @@ void reset_staging(hm_batch* b) {
     b->chunks.n = 0;
     b->rinfo.n = 0;
     b->tiles.n = 0;
+    b->tcost.n = 0;
     b->groups.clear();
     b->total_bases = 0;
     b->uploaded = b->ran = b->have_totals = b->have_calls = false;
@@ -490,18 +518,8 @@ int stage_read(hm_batch* b, int32_t read_id, int32_t l_qseq, int32_t flag, const
         const int ridx = (int)b->reads.n;
         // dense trunk: the read's maps cover view positions [-200, L + 200) in tiles of TR_OWN; a new group starts when
         // the current one holds group_bases
-        if (b->groups.empty() || b->groups.back().bases >= effective_group_bases(e))
-            b->groups.push_back(hm_batch::Group{(int)b->chunks.n, (int)b->chunks.n, (int)b->tiles.n, (int)b->tiles.n, 0, 0});
-        hm_batch::Group& g = b->groups.back();
-        const int ntile = (l_qseq + 2 * TR_PAD + TR_OWN - 1) / TR_OWN;
-        b->rinfo.push_back(RInfo{b->total_bases, l_qseq, (int32_t)g.rows});
-        for (int t = 0; t < ntile; ++t) b->tiles.push_back(TrunkTile{ridx, -TR_PAD + t * TR_OWN});
         b->reads.push_back(rd);
-        for (int st = 0; st < l_qseq; st += CHUNK) b->chunks.push_back(Chunk{ridx, st});
-        g.rows += (int64_t)ntile * TR_OWN + TR_SLACK;
-        g.bases += l_qseq;
-        g.chunk_hi = (int)b->chunks.n;
-        g.tile_hi = (int)b->tiles.n;
+        add_read_tiles(e, b, ridx, l_qseq);
         b->total_bases += (int64_t)((L + 3) & ~size_t(3));
     } catch (const HipErr& h) {
         return fail_hip(e, h);
@@ -537,6 +555,8 @@ void enqueue_upload(hm_batch* b) {
     b->d_tiles.reserve(std::max<size_t>(b->tiles.n, 1) * sizeof(TrunkTile));
     if (nr) HIP_TRY(hipMemcpyAsync(b->d_rinfo.p, b->rinfo.p, nr * sizeof(RInfo), hipMemcpyHostToDevice, b->s_io));
     if (b->tiles.n) HIP_TRY(hipMemcpyAsync(b->d_tiles.p, b->tiles.p, b->tiles.n * sizeof(TrunkTile), hipMemcpyHostToDevice, b->s_io));
+    b->d_tcost.reserve(std::max<size_t>(b->tcost.n, 1) * sizeof(int32_t));
+    if (b->tcost.n) HIP_TRY(hipMemcpyAsync(b->d_tcost.p, b->tcost.p, b->tcost.n * sizeof(int32_t), hipMemcpyHostToDevice, b->s_io));
     HIP_TRY(hipEventRecord(b->ev_in, b->s_io));
     b->uploaded = true;
     b->ran = b->have_totals = b->have_calls = false;
@@ -598,7 +618,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
                 if (e->trunk_impl == 3)
                     launch_trunk3(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
                                   b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->d_dump.as<uint16_t>(),
-                                  b->d_totals.as<int32_t>() + 8, e->num_cu);
+                                  b->d_totals.as<int32_t>() + 8, b->d_tcost.as<int32_t>() + g.cost_lo, e->num_cu);
                 else if (e->trunk_impl)
                     launch_trunk2(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
                                   b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->num_cu, w16,
@@ -1132,18 +1152,8 @@ int64_t hm_batch_submit_reads(hm_batch_t* b, const hm_read_t* reads, int64_t n, 
             rd.read_id = r.read_id;
             for (int k = 0; k < 4; ++k) rd.w[k] = r.width[k];
             const int ridx = (int)b->reads.n;
-            if (b->groups.empty() || b->groups.back().bases >= effective_group_bases(e))
-                b->groups.push_back(hm_batch::Group{(int)b->chunks.n, (int)b->chunks.n, (int)b->tiles.n, (int)b->tiles.n, 0, 0});
-            hm_batch::Group& g = b->groups.back();
-            const int ntile = (r.l_qseq + 2 * TR_PAD + TR_OWN - 1) / TR_OWN;
-            b->rinfo.push_back(RInfo{b->total_bases, r.l_qseq, (int32_t)g.rows});
-            for (int t = 0; t < ntile; ++t) b->tiles.push_back(TrunkTile{ridx, -TR_PAD + t * TR_OWN});
             b->reads.push_back(rd);
-            for (int st = 0; st < r.l_qseq; st += CHUNK) b->chunks.push_back(Chunk{ridx, st});
-            g.rows += (int64_t)ntile * TR_OWN + TR_SLACK;
-            g.bases += r.l_qseq;
-            g.chunk_hi = (int)b->chunks.n;
-            g.tile_hi = (int)b->tiles.n;
+            add_read_tiles(e, b, ridx, r.l_qseq);
             b->total_bases += (int64_t)((L + 3) & ~size_t(3));
             if (accepted) accepted[i] = 1;
             ++taken;

@@ -91,11 +91,12 @@ void launch_trunk2(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, 
 // the trunk as a sliding window (hm_trunk3.hip): a workgroup walks consecutive tiles and keeps every layer's right-hand rows, so that
 // each layer computes 112 rows per tile instead of 144 / 144 / 128 / 112: byte-identical maps, 14 % fewer MFMAs.  `maps.rowlist` must
 // hold trunk3_rowlist_bytes(n_tiles * n_views) bytes, `dump` trunk3_dump_bytes(grid); every read's map region needs 32 rows of slack at its end.
+// `tcost`: the running cost of the tiles (n_tiles + 1 entries from 0; hm_engine.cpp add_read_tiles) the workgroups' runs are cut by, or null (equal counts).
 size_t trunk3_rowlist_bytes(int64_t n_work);
 size_t trunk3_dump_bytes(int grid);
 void launch_trunk3(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w, const TrunkMaps& maps,
-                   uint16_t* dump, int32_t* list_steps, int grid);
+                   uint16_t* dump, int32_t* list_steps, const int32_t* tcost, int grid);
 // the same path in strict fp32 (precision 0; hm_trunk_f32.hip): fp32 maps and edge rows, v_mfma_f32_16x16x4_f32
 void launch_trunk_f32(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                       const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,

@@ -79,7 +79,7 @@ struct MGeo {
 
 struct HGeo {
     static constexpr int S = 16, NW = 4;
-    static constexpr int L6 = 7, L7 = 4, L8 = 2;
+    static constexpr int L7 = 4, L8 = 2;   // rows of conv7 / conv8 (conv6 hands over 7)
     static constexpr int RS96 = XS_RS96, RS64 = XS_RS64;
     // fc1's fp32 output for fc2: [site][8 parts][32 + 4 floats], and fc2's weights the same way.  A thread of fc2 sums 32 consecutive
     // k (tail_kernel_h's order); with the parts 128 bytes apart every ds_read_b128 of a lane group hit the same banks (8-way

@@ -110,6 +110,13 @@ struct CopyRows3 {
     half_t* g;            // map row of plane row 0
 };
 
+// workgroup barrier that orders LDS traffic only: vector-memory operations (a step's map-row stores) stay in flight across it
+__device__ __forceinline__ void t3_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // nrows whole rows (hi and lo plane) LDS -> LDS, 16 bytes per thread and round
 template <int NROWS, int NT, int K = 0>
 __device__ __forceinline__ void move_rows(half_t* dh, half_t* dl, const half_t* sh, const half_t* sl, int t) {
@@ -220,7 +227,7 @@ template <int K1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views, int ctx, const RInfo* __restrict__ rinfo,
                    const uint8_t* __restrict__ bases, const uint32_t* __restrict__ kin, CtxWeights W, TrunkMaps mp, half_t* __restrict__ dump,
-                   int32_t* __restrict__ list_steps) {
+                   int32_t* __restrict__ list_steps, const int32_t* __restrict__ tcost) {
     constexpr int NW = 4, NTW = 2;
     __shared__ __attribute__((aligned(16))) half_t smem[T3_LDS_HALVES + T3_XROWS * TR_WRS];
     static_assert(sizeof(smem) == 147840, "LDS plan");
@@ -240,9 +247,42 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     half_t* xb = h3_lo + T3_H3 * TR_RS;        // feature rows of the step (their own buffer: built while conv4 runs)
     const int n_work = n_tiles * n_views;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // a workgroup takes a contiguous run of tiles
-    const int base_n = n_work / (int)gridDim.x, rem_n = n_work - base_n * (int)gridDim.x;
-    const int w0 = (int)blockIdx.x * base_n + min((int)blockIdx.x, rem_n), w1 = w0 + base_n + ((int)blockIdx.x < rem_n);
+    // A workgroup takes a contiguous run of tiles: runs of equal COST (tcost: running cost of the group's tiles, n_tiles + 1 entries -- a
+    // constant step is an eighth of a computed one; with equal counts the workgroup with the fewest of them sets the launch's time).
+    // Workgroup k starts at the first work item w whose running cost reaches k / G of the total: a 64-ary search, every lane a probe.
+    int w0, w1;
+    if (tcost) {
+        const int64_t c_view = tcost[n_tiles], c_all = c_view * n_views;
+        auto cost_at = [&](const int wq) __attribute__((always_inline)) {   // running cost in front of work item wq (0 .. n_work)
+            const int v = wq >= n_tiles && wq < n_work ? 1 : wq >= n_work ? n_views : 0;
+            return v * c_view + (wq >= n_work ? 0 : tcost[wq - (v ? n_tiles : 0)]);
+        };
+        auto first_at = [&](const int64_t target) __attribute__((always_inline)) {
+            int lo = 0, hi = n_work;   // the answer lies in [lo, hi]; cost_at(hi) >= target
+            while (hi > lo) {
+                const int stride = (hi - lo + 63) / 64;
+                const int probe = lo + lane * stride;
+                const bool ge = probe >= hi || cost_at(probe) >= target;
+                const uint64_t bal = __ballot(ge);
+                const int first = bal ? __builtin_ctzll(bal) : 64;
+                if (first == 0) {
+                    hi = lo;
+                } else {
+                    const int nlo = lo + (first - 1) * stride + 1;
+                    hi = first < 64 ? min(lo + first * stride, hi) : hi;
+                    lo = nlo;
+                }
+            }
+            return __builtin_amdgcn_readfirstlane(lo);
+        };
+        const int64_t k = blockIdx.x, G = gridDim.x;
+        w0 = first_at((k * c_all + G - 1) / G);
+        w1 = k + 1 == G ? n_work : first_at(((k + 1) * c_all + G - 1) / G);
+    } else {
+        const int base_n = n_work / (int)gridDim.x, rem_n = n_work - base_n * (int)gridDim.x;
+        w0 = (int)blockIdx.x * base_n + min((int)blockIdx.x, rem_n);
+        w1 = w0 + base_n + ((int)blockIdx.x < rem_n);
+    }
     if (w0 >= w1) return;
 
     for (int i = threadIdx.x; i < (T3_LDS_HALVES + T3_XROWS * TR_WRS) / 2; i += NW * 64) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
@@ -253,7 +293,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     // latency is exposed (as in trunk2_kernel).  The step after (w, warm-up) is (w, tile); the step after (w, tile) is (w + 1, warm-up)
     // if tile w + 1 is a read's first, else (w + 1, tile).
     struct Build {
-        TrunkTile tl;
+        TrunkTile tl, tl2;  // the step's tile; the tile behind it in the list (a constant step builds its successor from it: no load to wait for)
         RInfo ri;
         int w, view, warm, cst, calib, ueff, b;
         uint32_t k, rl;
@@ -262,6 +302,8 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         bd.w = w;
         bd.view = w >= n_tiles;
         bd.tl = tiles[bd.view ? w - n_tiles : w];
+        const int w2 = min(w + 1, n_work - 1);
+        bd.tl2 = tiles[w2 >= n_tiles ? w2 - n_tiles : w2];
     };
     // prev_warm: the step being computed is a warm-up (then the next one is the tile itself)
     auto build_desc2 = [&](const int prev_warm, const bool first) __attribute__((always_inline)) {
@@ -343,7 +385,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
 #ifdef HM_TRUNK_STAMP
     // per layer: [0] barrier -> run returns, [3] wait at the next barrier; slot 22 / 23: s_memtime / s_memrealtime of the whole loop
     unsigned long long ts[10], acc_t[16] = {};
-    unsigned long long n_it = 0;
+    unsigned long long n_it = 0, acc_c = 0, n_c = 0;   // (acc_c, n_c: ticks and number of the constant steps, slots 17 / 18)
     const bool st_on = blockIdx.x == 0;
     const unsigned long long tk0 = hm_stamp(), tr0 = __builtin_amdgcn_s_memrealtime();
 #define TS(i) do { if (st_on) ts[i] = hm_stamp(); } while (0)
@@ -351,7 +393,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
 #define TS(i)
 #endif
     while (true) {
-        __syncthreads();  // the step's feature rows, lists and descriptors are in LDS; the previous step is through with the planes
+        t3_lds_barrier();  // the step's feature rows, lists and descriptors are in LDS; the previous step is through with the planes (its stores may still drain)
         TS(0);
         const int64_t grow0 = s_grow0;
         const int kind = __builtin_amdgcn_readfirstlane(s_kind);
@@ -379,10 +421,32 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
         half_t* g3 = cur_calib ? dump_rows : reinterpret_cast<half_t*>(mp.e[2]) + grow0 * 256;             // plane A row 0 as E3 = position u
         const uint8_t* rl = reinterpret_cast<const uint8_t*>(rlist[buf]);
         if (cur_const) {
-            // ---- a constant step: nothing to compute.  Its stores first: they drain while the next step's descriptors (three dependent
-            // loads, this step's length) arrive ----
+            // ---- a constant step: nothing to compute.  The next step's descriptor comes from what is at hand (bd still describes this
+            // step): the same tile (this was its warm-up step) or the tile behind it (fetched a step ago), the read's record only if the
+            // read changes.  Its loads go out in front of this step's stores; the stores drain while they arrive ----
             const int t = threadIdx.x;
             n_const += !cur_warm;  // (tiles: a read's warm-up step is no tile)
+            const int wb = min(wn, w1 - 1);
+            bool new_read = false;
+            if (wb != bd.w) {
+                const int prev_read = bd.tl.read_idx;
+                bd.w = wb;
+                bd.view = wb >= n_tiles;
+                bd.tl.read_idx = __builtin_amdgcn_readfirstlane(bd.tl2.read_idx);
+                bd.tl.u0 = __builtin_amdgcn_readfirstlane(bd.tl2.u0);
+                const int w2 = min(wb + 1, n_work - 1);
+                bd.tl2 = tiles[w2 >= n_tiles ? w2 - n_tiles : w2];
+                new_read = bd.tl.read_idx != prev_read;
+                if (new_read) bd.ri = rinfo[bd.tl.read_idx];
+            }
+            auto finish_desc = [&]() __attribute__((always_inline)) {
+                bd.warm = cur_warm ? 0 : (bd.tl.u0 == -TR_PAD);
+                bd.calib = 0;
+                bd.ueff = bd.tl.u0 - (bd.warm ? TR_OWN : 0);
+                bd.cst = bd.tl.u0 == -TR_PAD || (!bd.warm && bd.tl.u0 >= bd.ri.len);
+                build_loads();
+            };
+            if (!new_read) finish_desc();
             if (!cur_warm) {  // the tile's E4 rows (a read's warm-up step lies in front of its region)
                 uint4* g4 = reinterpret_cast<uint4*>(reinterpret_cast<half_t*>(mp.e4) + grow0 * (2 * C4_CH));
                 const uint4 v = reinterpret_cast<const uint4*>(e4c)[t % 24];   // (256 = 16 mod 24: a thread's chunk column moves by 16 per round)
@@ -400,10 +464,12 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
                 half_t* g = l == 0 ? g1 : l == 1 ? g2 : g3;
                 const int fill = first_new[l] + TR_OWN - 1, ch = t & 31;
                 const uint4 v = reinterpret_cast<const uint4*>(&kc[l][0][0])[ch];
-                for (int e = t >> 5; e < TR_OWN; e += 8) {
-                    const int p = rows[e];
-                    if (p != fill) reinterpret_cast<uint4*>(g + (size_t)p * 256)[ch] = v;
-                }
+                int pr[TR_OWN / 8];   // (the 14 entries of this thread's row group are read before the first is used)
+#pragma unroll
+                for (int i = 0; i < TR_OWN / 8; ++i) pr[i] = rows[(t >> 5) + 8 * i];
+#pragma unroll
+                for (int i = 0; i < TR_OWN / 8; ++i)
+                    if (pr[i] != fill) reinterpret_cast<uint4*>(g + (size_t)pr[i] * 256)[ch] = v;
                 if (t < 32) reinterpret_cast<uint4*>(g + (size_t)fill * 256)[ch] = v;  // (the last new row may be flagged itself)
             }
             // the kept rows of the step behind this one: 4 + 8 + 16 rows of constants
@@ -413,13 +479,19 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
                 half_t* dst = (l == 0 ? (plane ? h1_lo : h1_hi) : l == 1 ? (plane ? b_lo : b_hi) : (plane ? h3_lo : h3_hi)) + r * TR_RS + col;
                 *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&kc[l][plane][col]);
             }
-            build_desc1(min(wn, w1 - 1));
-            build_desc2(cur_warm, false);
-            build_desc3();
-            build_loads();
-            __syncthreads();  // every wave has read this step's record and kind
+            if (new_read) {
+                build_desc3();
+                finish_desc();
+            }
+            t3_lds_barrier();  // every wave has read this step's record and kind
             build_store(buf ^ 1);
             buf ^= 1;
+#ifdef HM_TRUNK_STAMP
+            if (st_on) {
+                acc_c += hm_stamp() - ts[0];
+                ++n_c;
+            }
+#endif
             if (last) break;
             w = wn;
             warm = bd.warm;
@@ -504,6 +576,8 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
     if (st_on && (threadIdx.x & 63) == 0) {
         for (int i = 0; i < 16; ++i) atomicAdd(&g_trunk3_stamp[threadIdx.x >> 6][i], acc_t[i]);
         atomicAdd(&g_trunk3_stamp[threadIdx.x >> 6][16], n_it);
+        atomicAdd(&g_trunk3_stamp[threadIdx.x >> 6][17], acc_c);
+        atomicAdd(&g_trunk3_stamp[threadIdx.x >> 6][18], n_c);
         atomicAdd(&g_trunk3_stamp[threadIdx.x >> 6][22], hm_stamp() - tk0);
         atomicAdd(&g_trunk3_stamp[threadIdx.x >> 6][23], __builtin_amdgcn_s_memrealtime() - tr0);
     }
@@ -518,16 +592,16 @@ size_t trunk3_dump_bytes(int grid) { return ((size_t)(1 + grid) * TR_OWN * 2 * C
 
 void launch_trunk3(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w, const TrunkMaps& maps,
-                   uint16_t* dump, int32_t* list_steps, int grid) {
+                   uint16_t* dump, int32_t* list_steps, const int32_t* tcost, int grid) {
     if (n_tiles <= 0) return;
     const int n_work = n_tiles * n_views;
     const dim3 g(min(n_work, grid));
     if (k1 == 11) {
         hipLaunchKernelGGL(rowlist3_kernel<11>, dim3(2 * n_work + 1), dim3(128), 0, st, tiles, n_tiles, n_work, ctx, rinfo, bases, sctx, maps.rowlist);
-        hipLaunchKernelGGL(trunk3_kernel<11>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps);
+        hipLaunchKernelGGL(trunk3_kernel<11>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps, tcost);
     } else {
         hipLaunchKernelGGL(rowlist3_kernel<13>, dim3(2 * n_work + 1), dim3(128), 0, st, tiles, n_tiles, n_work, ctx, rinfo, bases, sctx, maps.rowlist);
-        hipLaunchKernelGGL(trunk3_kernel<13>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps);
+        hipLaunchKernelGGL(trunk3_kernel<13>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps, tcost);
     }
 }
 

@@ -36,6 +36,8 @@ for l in range(4):
         tot += v
         print(f"conv{l + 1} {nm:9s} " + " ".join(f"{x:7.0f}" for x in v))
 print("sum            " + " ".join(f"{x:7.0f}" for x in tot))
+if buf[0, 18]:
+    print("constant steps of workgroup 0:", int(buf[0, 18]), " ticks each " + " ".join(f"{float(buf[w, 17]) / float(buf[w, 18]):7.0f}" for w in range(4)))
 print(f"in-kernel clock of workgroup 0's step loops: {float(buf[0, 22]) / max(float(buf[0, 23]), 1) * 0.1:.3f} GHz (s_memtime / s_memrealtime x 100 MHz)")
 tm = mc.timing()
 print("trunk_ms per run", [round(x / 3, 2) for x in tm["trunk_ms"]], "listed-row steps", tm["trunk_list_steps"], "tiles", [p // 112 for p in tm["trunk_positions"]])
