@@ -136,90 +136,125 @@ __device__ __forceinline__ void move_rows(half_t* dh, half_t* dl, const half_t* 
 // ones first, the rest filled with the LAST new row (a row that is always valid and never touched by a warm-up step's garbage; storing
 // it once more is harmless).  Block w < n_work: the step of tile w; block n_work + w: the warm-up step in front of a read's first
 // tile (u - 112); block 2 n_work: the list of a warm-up step in the middle of a read (a workgroup's first tile): nothing but fill.
+// One WAVE makes T3_RPB consecutive step records.  The kernel waits on three dependent loads per record -- tile, read, site flags -- so its
+// rate is the number of records in flight: the wave issues each of the three for all its records before it uses the first (one-wave
+// blocks: 32 per CU).  Lane r owns rows r and r + 64 of a record; a record is assembled in LDS and leaves as 101 coalesced words.
+constexpr int T3_RPB = 4;
 template <int K1>
-__global__ __launch_bounds__(128) void rowlist3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_work, int ctx,
-                                                        const RInfo* __restrict__ rinfo, const uint8_t* __restrict__ bases,
-                                                        const uint8_t* __restrict__ sctx, uint8_t* __restrict__ rowlist) {
+__global__ __launch_bounds__(64) void rowlist3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_work, int ctx,
+                                                       const RInfo* __restrict__ rinfo, const uint8_t* __restrict__ bases,
+                                                       const uint8_t* __restrict__ sctx, uint8_t* __restrict__ rowlist) {
     using G = EdgeGeo<K1>;
-    __shared__ int cnt0[3];
-    const int blk = blockIdx.x, r = threadIdx.x;
-    uint8_t* out = rowlist + (size_t)blk * T3_RL;
+    const int r = threadIdx.x;
     constexpr int first_new[3] = {T3_H1, T3_H2, T3_H3}, shift[3] = {T3_S1, T3_S2, T3_S3};
-    if (blk == 2 * n_work) {
-        for (int i = r; i < T3_RL3; i += 128) out[i] = (uint8_t)(first_new[i / TR_OWN] + TR_OWN - 1);
-        if (r == 0) *reinterpret_cast<uint32_t*>(out + T3_RL3 + T3_N4) = 255u;
-        return;
-    }
-    const bool warm = blk >= n_work;
-    const int w = warm ? blk - n_work : blk, view = w >= n_tiles;
-    const TrunkTile tl = tiles[view ? w - n_tiles : w];
-    if (warm && tl.u0 != -TR_PAD) return;  // (only a read's first tile has a warm-up step that stores map rows)
-    const RInfo ri = rinfo[tl.read_idx];
-    const int L = ri.len, u = tl.u0 - (warm ? TR_OWN : 0), want_base = view ? 2 : 1;
-    auto site_at = [&](int y) __attribute__((always_inline)) {
-        if (y < 0 || y >= L) return 0;
-        const int64_t j = ri.base_off + (view ? L - 1 - y : y);
-        return (int)(sctx[j] == ctx && bases[j] == want_base);
-    };
-    // the site flags of every position any lookup of this block can touch go through LDS once: [u - 176, u + 352)
-    constexpr int W0 = -176, WN = 528;
-    __shared__ uint8_t sf[WN];
-    for (int i = r; i < WN; i += 128) sf[i] = (uint8_t)site_at(u + W0 + i);
-    for (int i = r; i < T3_RL3; i += 128) out[i] = (uint8_t)(first_new[i / TR_OWN] + TR_OWN - 1);
-    __syncthreads();
-    auto sat = [&](int y) __attribute__((always_inline)) { return (int)sf[y - u - W0]; };   // y - u in [W0, W0 + WN)
+    constexpr int W0 = -176, WN = 528;   // the site flags of every position any lookup of a record can touch go through LDS once: [u - 176, u + 352)
+    __shared__ __attribute__((aligned(4))) uint8_t rec[T3_RPB][T3_RL];
+    __shared__ uint8_t sf[T3_RPB][WN];
     static_assert(-G::R1 - 2 + T3_S1 >= W0 && -G::R2 - 4 + T3_S2 >= W0 && -G::R3 - 8 + T3_S3 >= W0 && T3_S1 + TR_OWN - 1 - G::LEFT < W0 + WN &&
                   215 - 16 * 23 >= W0 && TR_OWN - 1 + 215 - 16 < W0 + WN, "the window covers every lookup");
-    int f = 0;
-    if (r < TR_OWN) {
-        {
-            const int x = u + shift[0] + r;
-            f |= (sat(x - G::LEFT) | sat(x - G::R1) | (G::PAD2 ? 0 : sat(x - G::R1 - 2))) << 0;
-        }
-        {
-            const int x = u + shift[1] + r;
-            f |= (sat(x - G::LEFT) | sat(x - G::R2) | (G::PAD3 ? 0 : sat(x - G::R2 - 4))) << 1;
-        }
-        {
-            const int x = u + shift[2] + r;
-            f |= (sat(x - G::LEFT) | sat(x - G::R3) | (G::PAD4 ? 0 : sat(x - G::R3 - 8))) << 2;
+    // record blk < n_work: the step of tile blk; n_work + w: the warm-up step in front of a read's first tile; 2 n_work: nothing but fill
+    int kind[T3_RPB];   // 0: nothing to do, 1: a list record, 2: the all-fill record
+    TrunkTile tl[T3_RPB];
+    RInfo ri[T3_RPB];
+    bool warm[T3_RPB];
+    int view[T3_RPB];
+#pragma unroll
+    for (int k = 0; k < T3_RPB; ++k) {
+        const int blk = (int)blockIdx.x * T3_RPB + k;
+        kind[k] = blk > 2 * n_work ? 0 : blk == 2 * n_work ? 2 : 1;
+        warm[k] = blk >= n_work;
+        const int w = min(warm[k] ? blk - n_work : blk, n_work - 1);
+        view[k] = w >= n_tiles;
+        tl[k] = tiles[view[k] ? w - n_tiles : w];
+    }
+#pragma unroll
+    for (int k = 0; k < T3_RPB; ++k) {
+        if (kind[k] == 1 && warm[k] && tl[k].u0 != -TR_PAD) kind[k] = 0;  // (only a read's first tile has a warm-up step that stores map rows)
+        ri[k] = rinfo[tl[k].read_idx];
+    }
+    // (every record's loads are issued -- at clamped, valid addresses whatever the record's kind -- before the first is used)
+    constexpr int NQ = (WN + 63) / 64;
+    uint8_t sc[T3_RPB][NQ], bs[T3_RPB][NQ];
+#pragma unroll
+    for (int k = 0; k < T3_RPB; ++k) {
+        const int L = ri[k].len, u = tl[k].u0 - (warm[k] ? TR_OWN : 0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int yc = min(max(u + W0 + r + 64 * q, 0), L - 1);
+            const int64_t j = ri[k].base_off + (view[k] ? L - 1 - yc : yc);
+            sc[k][q] = sctx[j];
+            bs[k][q] = bases[j];
         }
     }
-    // E4 rows some site of this context reads: position x is row s of the site at x + 215 - 16 s (s = 1 .. 23: rows 0 and 24 are the edge
-    // kernel's).  Not for CHH (K1 = 13: at its density nearly every row is read) nor for warm-up steps (their E4 rows go to the dump): a
-    // count of 255 keeps the step on all 112 rows.
-    int need4 = 0;
-    const bool want4 = K1 == 11 && !warm;
-    if (want4 && r < TR_OWN) {
 #pragma unroll
-        for (int sidx = 1; sidx <= 23; ++sidx) need4 |= sat(u + r + 215 - 16 * sidx);
+    for (int k = 0; k < T3_RPB; ++k) {
+        for (int i = r; i < T3_RL3; i += 64) rec[k][i] = (uint8_t)(first_new[i / TR_OWN] + TR_OWN - 1);
+        const int L = ri[k].len, u = tl[k].u0 - (warm[k] ? TR_OWN : 0), want_base = view[k] ? 2 : 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int y = u + W0 + r + 64 * q;
+            if (r + 64 * q < WN) sf[k][r + 64 * q] = (uint8_t)(sc[k][q] == ctx && bs[k][q] == want_base && y >= 0 && y < L);
+        }
     }
-    uint64_t bal[3];
-#pragma unroll
-    for (int l = 0; l < 3; ++l) bal[l] = __ballot((f >> l) & 1);
-    if (r < 3) cnt0[r] = 0;
     __syncthreads();
-    const uint64_t bal4 = __ballot(need4);
-    __shared__ int cnt4[2];
-    if (r == 0) {
+    const uint64_t below = (1ull << r) - 1;
 #pragma unroll
-        for (int l = 0; l < 3; ++l) cnt0[l] = __popcll(bal[l]);
-    }
-    if ((r & 63) == 0) cnt4[r >> 6] = __popcll(bal4);
-    __syncthreads();
-    const int lane = r & 63;
+    for (int k = 0; k < T3_RPB; ++k) {
+        if (kind[k] == 0) continue;
+        const int blk = (int)blockIdx.x * T3_RPB + k;
+        int n4 = 255;
+        if (kind[k] == 1) {
+            const int u = tl[k].u0 - (warm[k] ? TR_OWN : 0);
+            auto sat = [&](int y) __attribute__((always_inline)) { return (int)sf[k][y - u - W0]; };   // y - u in [W0, W0 + WN)
+            // E4 rows some site of this context reads: position x is row s of the site at x + 215 - 16 s (s = 1 .. 23: rows 0 and 24 are the
+            // edge kernel's).  Not for CHH (K1 = 13: at its density nearly every row is read) nor for warm-up steps (their E4 rows go to the
+            // dump): a count of 255 keeps the step on all 112 rows.
+            const bool want4 = K1 == 11 && !warm[k];
+            int f[2] = {0, 0}, need4[2] = {0, 0};
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
-        if ((f >> l) & 1) out[l * TR_OWN + (r >= 64 ? cnt0[l] : 0) + __popcll(bal[l] & ((1ull << lane) - 1))] = (uint8_t)(first_new[l] + r);
-    // the E4 list: the needed rows in ascending order, filled up with the first of them (a row is stored twice: harmless)
-    const int n4 = want4 ? cnt4[0] + cnt4[1] : 255;
-    if (want4 && n4 <= T3_N4) {
-        const int at = (r >= 64 ? cnt4[0] : 0) + __popcll(bal4 & ((1ull << lane) - 1));
-        if (need4) out[T3_RL3 + at] = (uint8_t)r;
+            for (int h = 0; h < 2; ++h) {
+                const int row = r + 64 * h;
+                if (row < TR_OWN) {
+                    {
+                        const int x = u + shift[0] + row;
+                        f[h] |= (sat(x - G::LEFT) | sat(x - G::R1) | (G::PAD2 ? 0 : sat(x - G::R1 - 2))) << 0;
+                    }
+                    {
+                        const int x = u + shift[1] + row;
+                        f[h] |= (sat(x - G::LEFT) | sat(x - G::R2) | (G::PAD3 ? 0 : sat(x - G::R2 - 4))) << 1;
+                    }
+                    {
+                        const int x = u + shift[2] + row;
+                        f[h] |= (sat(x - G::LEFT) | sat(x - G::R3) | (G::PAD4 ? 0 : sat(x - G::R3 - 8))) << 2;
+                    }
+                    if (want4) {
+#pragma unroll
+                        for (int sidx = 1; sidx <= 23; ++sidx) need4[h] |= sat(u + row + 215 - 16 * sidx);
+                    }
+                }
+            }
+            // per layer: the flagged rows first, in ascending order (the rest of the list keeps the fill entry written above)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const uint64_t b0 = __ballot((f[0] >> l) & 1), b1 = __ballot((f[1] >> l) & 1);
+                if ((f[0] >> l) & 1) rec[k][l * TR_OWN + __popcll(b0 & below)] = (uint8_t)(first_new[l] + r);
+                if ((f[1] >> l) & 1) rec[k][l * TR_OWN + __popcll(b0) + __popcll(b1 & below)] = (uint8_t)(first_new[l] + r + 64);
+            }
+            // the E4 list: the needed rows in ascending order, filled up with the first of them (a row is stored twice: harmless)
+            const uint64_t n0 = __ballot(need4[0]), n1 = __ballot(need4[1]);
+            if (want4) n4 = __popcll(n0) + __popcll(n1);
+            if (want4 && n4 <= T3_N4) {
+                if (need4[0]) rec[k][T3_RL3 + __popcll(n0 & below)] = (uint8_t)r;
+                if (need4[1]) rec[k][T3_RL3 + __popcll(n0) + __popcll(n1 & below)] = (uint8_t)(r + 64);
+                __syncthreads();
+                if (r >= n4) rec[k][T3_RL3 + r] = n4 > 0 ? rec[k][T3_RL3] : (uint8_t)0;   // (r < 64 = T3_N4)
+            }
+        }
+        if (r == 0) *reinterpret_cast<uint32_t*>(&rec[k][T3_RL3 + T3_N4]) = (uint32_t)n4;
         __syncthreads();
-        if (r >= n4 && r < T3_N4) out[T3_RL3 + r] = n4 > 0 ? out[T3_RL3] : (uint8_t)0;
+        uint32_t* out = reinterpret_cast<uint32_t*>(rowlist + (size_t)blk * T3_RL);
+        for (int i = r; i < T3_RL / 4; i += 64) out[i] = reinterpret_cast<const uint32_t*>(rec[k])[i];   // (a dense step's E4 list is never read)
     }
-    if (r == 0) *reinterpret_cast<uint32_t*>(out + T3_RL3 + T3_N4) = (uint32_t)n4;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -597,10 +632,10 @@ void launch_trunk3(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, 
     const int n_work = n_tiles * n_views;
     const dim3 g(min(n_work, grid));
     if (k1 == 11) {
-        hipLaunchKernelGGL(rowlist3_kernel<11>, dim3(2 * n_work + 1), dim3(128), 0, st, tiles, n_tiles, n_work, ctx, rinfo, bases, sctx, maps.rowlist);
+        hipLaunchKernelGGL(rowlist3_kernel<11>, dim3((2 * n_work + T3_RPB) / T3_RPB), dim3(64), 0, st, tiles, n_tiles, n_work, ctx, rinfo, bases, sctx, maps.rowlist);
         hipLaunchKernelGGL(trunk3_kernel<11>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps, tcost);
     } else {
-        hipLaunchKernelGGL(rowlist3_kernel<13>, dim3(2 * n_work + 1), dim3(128), 0, st, tiles, n_tiles, n_work, ctx, rinfo, bases, sctx, maps.rowlist);
+        hipLaunchKernelGGL(rowlist3_kernel<13>, dim3((2 * n_work + T3_RPB) / T3_RPB), dim3(64), 0, st, tiles, n_tiles, n_work, ctx, rinfo, bases, sctx, maps.rowlist);
         hipLaunchKernelGGL(trunk3_kernel<13>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps, tcost);
     }
 }
