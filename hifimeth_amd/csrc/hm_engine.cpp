@@ -617,7 +617,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
                 Span sp(e, spans, K_TRUNK, c, 0, (int64_t)n_tiles * TR_OWN * n_views);
                 if (e->trunk_impl == 3)
                     launch_trunk3(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
-                                  b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->d_dump.as<uint16_t>(),
+                                  b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), b->total_bases, dm.w, maps, e->d_dump.as<uint16_t>(),
                                   b->d_totals.as<int32_t>() + 8, b->d_tcost.as<int32_t>() + g.cost_lo, e->num_cu);
                 else if (e->trunk_impl)
                     launch_trunk2(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),

@@ -9,7 +9,8 @@ namespace hm {
 // feature extraction -------------------------------------------------------------------------
 // A: decode 4-bit bases to forward-strand codes, pack the four kinetics arrays per forward
 //    position, count sites per 1024-base chunk.
-//    sctx[j] = context of the site at forward position j (CTX_NONE = 3: no site, or its context is masked out).
+//    sctx[j] = context of the site at forward position j (CTX_NONE = 3: no site, or its context is masked out) | strand << 2
+//    (strand 1: the base is a G, the cytosine sits on the reverse strand): a site of context c in strand view v reads c | v << 2.
 void launch_prep(hipStream_t st, const uint8_t* raw, const ReadDesc* reads, const Chunk* chunks, int n_chunks,
                  int ctx_mask, uint8_t* bases, uint32_t* kin, uint8_t* sctx, int32_t* chunk_counts, int32_t* err);
 // S: exclusive scan of the NCNT chunk counters -> chunk offsets [n_chunks + 1][NCNT] (last row = totals),
@@ -95,8 +96,8 @@ void launch_trunk2(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, 
 size_t trunk3_rowlist_bytes(int64_t n_work);
 size_t trunk3_dump_bytes(int grid);
 void launch_trunk3(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
-                   const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w, const TrunkMaps& maps,
-                   uint16_t* dump, int32_t* list_steps, const int32_t* tcost, int grid);
+                   const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, int64_t n_bases, const CtxWeights& w, const TrunkMaps& maps,
+                   uint16_t* dump, int32_t* list_steps, const int32_t* tcost, int grid);   // n_bases: bytes of sctx
 // the same path in strict fp32 (precision 0; hm_trunk_f32.hip): fp32 maps and edge rows, v_mfma_f32_16x16x4_f32
 void launch_trunk_f32(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                       const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(const uint8_t* __res
                     ++my[cls];
                     if (c[t + 2] == 2) ++my[3];  // forward G: the cytosine sits on the reverse strand
                 }
-                cpack |= (uint32_t)cls << (8 * t);
+                cpack |= (uint32_t)(cls | (c[t + 2] == 2 ? 4 : 0)) << (8 * t);   // context | strand << 2
             } else {
                 cpack |= (uint32_t)CTX_NONE << (8 * t);
             }

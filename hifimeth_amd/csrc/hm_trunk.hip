@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512) void trunk_kernel(const TrunkTile* __restrict_
         auto site_at = [&](int y) __attribute__((always_inline)) {  // is view position y a site of this context?
             if (y < 0 || y >= L) return 0;
             const int64_t j = bo + (view ? L - 1 - y : y);
-            return (int)(sctx[j] == ctx && bases[j] == want_base);
+            return (int)(sctx[j] == (ctx | (want_base == 2 ? 4 : 0)));   // context | strand << 2 (hm_kernels.h)
         };
         for (int r = t; r < TR_XROWS; r += nt) {
             const int x = tl.u0 + r;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(128) void rowlist_kernel(const TrunkTile* __restric
     auto site_at = [&](int y) __attribute__((always_inline)) {
         if (y < 0 || y >= L) return 0;
         const int64_t j = ri.base_off + (view ? L - 1 - y : y);
-        return (int)(sctx[j] == ctx && bases[j] == want_base);
+        return (int)(sctx[j] == (ctx | (want_base == 2 ? 4 : 0)));   // context | strand << 2 (hm_kernels.h)
     };
     int f = 0;
     if (r < TR_OWN) {

@@ -142,14 +142,14 @@ __device__ __forceinline__ void move_rows(half_t* dh, half_t* dl, const half_t* 
 constexpr int T3_RPB = 4;
 template <int K1>
 __global__ __launch_bounds__(64) void rowlist3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_work, int ctx,
-                                                       const RInfo* __restrict__ rinfo, const uint8_t* __restrict__ bases,
-                                                       const uint8_t* __restrict__ sctx, uint8_t* __restrict__ rowlist) {
+                                                       const RInfo* __restrict__ rinfo, const uint8_t* __restrict__ sctx, int64_t n_bases,
+                                                       uint8_t* __restrict__ rowlist) {
     using G = EdgeGeo<K1>;
     const int r = threadIdx.x;
     constexpr int first_new[3] = {T3_H1, T3_H2, T3_H3}, shift[3] = {T3_S1, T3_S2, T3_S3};
     constexpr int W0 = -176, WN = 528;   // the site flags of every position any lookup of a record can touch go through LDS once: [u - 176, u + 352)
     __shared__ __attribute__((aligned(4))) uint8_t rec[T3_RPB][T3_RL];
-    __shared__ uint8_t sf[T3_RPB][WN];
+    __shared__ __attribute__((aligned(4))) uint8_t sf[T3_RPB][WN];
     static_assert(-G::R1 - 2 + T3_S1 >= W0 && -G::R2 - 4 + T3_S2 >= W0 && -G::R3 - 8 + T3_S3 >= W0 && T3_S1 + TR_OWN - 1 - G::LEFT < W0 + WN &&
                   215 - 16 * 23 >= W0 && TR_OWN - 1 + 215 - 16 < W0 + WN, "the window covers every lookup");
     // record blk < n_work: the step of tile blk; n_work + w: the warm-up step in front of a read's first tile; 2 n_work: nothing but fill
@@ -167,33 +167,59 @@ __global__ __launch_bounds__(64) void rowlist3_kernel(const TrunkTile* __restric
         view[k] = w >= n_tiles;
         tl[k] = tiles[view[k] ? w - n_tiles : w];
     }
+    bool any = false;
 #pragma unroll
     for (int k = 0; k < T3_RPB; ++k) {
         if (kind[k] == 1 && warm[k] && tl[k].u0 != -TR_PAD) kind[k] = 0;  // (only a read's first tile has a warm-up step that stores map rows)
-        ri[k] = rinfo[tl[k].read_idx];
+        any |= kind[k] != 0;
     }
-    // (every record's loads are issued -- at clamped, valid addresses whatever the record's kind -- before the first is used)
-    constexpr int NQ = (WN + 63) / 64;
-    uint8_t sc[T3_RPB][NQ], bs[T3_RPB][NQ];
+    if (!any) return;   // (most blocks of the warm-up range: one tile in ~140 is a read's first)
+#pragma unroll
+    for (int k = 0; k < T3_RPB; ++k) ri[k] = rinfo[tl[k].read_idx];
+    // The site bytes of a record's window, four positions per lane and load: sctx[j] = context | strand << 2 of forward position j
+    // (hm_kernels.h), so view position y is a site of this context and view iff its byte equals ctx | view << 2.  View 0 walks the
+    // array forwards from a 4-aligned address (read offsets, tile starts and the window's are multiples of 4); view 1 walks it
+    // backwards (y -> L - 1 - y: an unaligned word, bytes swapped).  Every record's loads are issued -- at addresses inside the array
+    // whatever the record's kind -- before the first is used; bytes of positions outside the read are masked afterwards.
+    constexpr int NQ = (WN / 4 + 63) / 64;
+    static_assert(WN % 4 == 0 && (-W0) % 4 == 0 && TR_PAD % 4 == 0 && TR_OWN % 4 == 0, "windows start on multiples of 4");
+    uint32_t sw[T3_RPB][NQ];
 #pragma unroll
     for (int k = 0; k < T3_RPB; ++k) {
         const int L = ri[k].len, u = tl[k].u0 - (warm[k] ? TR_OWN : 0);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int yc = min(max(u + W0 + r + 64 * q, 0), L - 1);
-            const int64_t j = ri[k].base_off + (view[k] ? L - 1 - yc : yc);
-            sc[k][q] = sctx[j];
-            bs[k][q] = bases[j];
+            const int y0 = u + W0 + 4 * (r + 64 * q);   // the word's first view position
+            const int64_t a = view[k] ? ri[k].base_off + (L - 1 - y0 - 3) : ri[k].base_off + y0;
+            if (a >= 0 && a + 4 <= n_bases) {
+                uint32_t v;
+                __builtin_memcpy(&v, sctx + a, 4);
+                sw[k][q] = view[k] ? __builtin_bswap32(v) : v;
+            } else {   // at the array's ends: byte by byte (positions outside the array are outside the read)
+                uint32_t v = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int64_t j = view[k] ? ri[k].base_off + (L - 1 - y0 - t) : ri[k].base_off + y0 + t;
+                    v |= (uint32_t)(j >= 0 && j < n_bases ? sctx[j] : (uint8_t)CTX_NONE) << (8 * t);
+                }
+                sw[k][q] = v;
+            }
         }
     }
 #pragma unroll
     for (int k = 0; k < T3_RPB; ++k) {
         for (int i = r; i < T3_RL3; i += 64) rec[k][i] = (uint8_t)(first_new[i / TR_OWN] + TR_OWN - 1);
-        const int L = ri[k].len, u = tl[k].u0 - (warm[k] ? TR_OWN : 0), want_base = view[k] ? 2 : 1;
+        const int L = ri[k].len, u = tl[k].u0 - (warm[k] ? TR_OWN : 0);
+        const uint32_t key = (uint32_t)(ctx | (view[k] << 2)) * 0x01010101u;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int y = u + W0 + r + 64 * q;
-            if (r + 64 * q < WN) sf[k][r + 64 * q] = (uint8_t)(sc[k][q] == ctx && bs[k][q] == want_base && y >= 0 && y < L);
+            const int y0 = u + W0 + 4 * (r + 64 * q);
+            const uint32_t x = sw[k][q] ^ key;                                               // a zero byte where the position is a site
+            uint32_t hit = (~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu)) >> 7;    // 1 in exactly those bytes
+            const int lo = min(max(-y0, 0), 4), hi = min(max(L - y0, 0), 4);                 // bytes [lo, hi) lie inside the read
+            const uint32_t m_hi = hi >= 4 ? 0xFFFFFFFFu : (1u << (8 * hi)) - 1u, m_lo = lo >= 4 ? 0xFFFFFFFFu : (1u << (8 * lo)) - 1u;
+            hit &= m_hi & ~m_lo;
+            if (r + 64 * q < WN / 4) reinterpret_cast<uint32_t*>(sf[k])[r + 64 * q] = hit;
         }
     }
     __syncthreads();
@@ -626,16 +652,16 @@ size_t trunk3_rowlist_bytes(int64_t n_work) { return (size_t)(2 * n_work + 1) * 
 size_t trunk3_dump_bytes(int grid) { return ((size_t)(1 + grid) * TR_OWN * 2 * C4_CH + 128 * 256) * sizeof(uint16_t); }
 
 void launch_trunk3(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
-                   const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w, const TrunkMaps& maps,
+                   const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, int64_t n_bases, const CtxWeights& w, const TrunkMaps& maps,
                    uint16_t* dump, int32_t* list_steps, const int32_t* tcost, int grid) {
     if (n_tiles <= 0) return;
     const int n_work = n_tiles * n_views;
     const dim3 g(min(n_work, grid));
     if (k1 == 11) {
-        hipLaunchKernelGGL(rowlist3_kernel<11>, dim3((2 * n_work + T3_RPB) / T3_RPB), dim3(64), 0, st, tiles, n_tiles, n_work, ctx, rinfo, bases, sctx, maps.rowlist);
+        hipLaunchKernelGGL(rowlist3_kernel<11>, dim3((2 * n_work + T3_RPB) / T3_RPB), dim3(64), 0, st, tiles, n_tiles, n_work, ctx, rinfo, sctx, n_bases, maps.rowlist);
         hipLaunchKernelGGL(trunk3_kernel<11>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps, tcost);
     } else {
-        hipLaunchKernelGGL(rowlist3_kernel<13>, dim3((2 * n_work + T3_RPB) / T3_RPB), dim3(64), 0, st, tiles, n_tiles, n_work, ctx, rinfo, bases, sctx, maps.rowlist);
+        hipLaunchKernelGGL(rowlist3_kernel<13>, dim3((2 * n_work + T3_RPB) / T3_RPB), dim3(64), 0, st, tiles, n_tiles, n_work, ctx, rinfo, sctx, n_bases, maps.rowlist);
         hipLaunchKernelGGL(trunk3_kernel<13>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps, tcost);
     }
 }

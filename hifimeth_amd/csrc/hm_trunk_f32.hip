@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512) void trunk_kernel_f32(const TrunkTile* __restr
         auto site_at = [&](int y) __attribute__((always_inline)) {
             if (y < 0 || y >= L) return 0;
             const int64_t j = bo + (view ? L - 1 - y : y);
-            return (int)(sctx[j] == ctx && bases[j] == want_base);
+            return (int)(sctx[j] == (ctx | (want_base == 2 ? 4 : 0)));   // context | strand << 2 (hm_kernels.h)
         };
         for (int r = t; r < F_XROWS; r += nt) {
             const int x = tl.u0 + r;
