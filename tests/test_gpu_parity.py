@@ -279,6 +279,21 @@ def test_fp16_weight_modes_are_closed(mc):
     mc.set_option("precision", mc.precision)
 
 
+def test_group_size_option_is_bounded():
+    """group_bases: 0 = sized from free device memory; an explicit size is capped at 48 Mi bases (190 GB of maps; the edge kernel addresses
+    a group's map rows in 27 bits).  Out-of-range values are errors, and the engine keeps working afterwards."""
+    from hifimeth_amd import HifimethError, MethylationCaller
+    with MethylationCaller(device=0, timing=True) as m:
+        for bad in (-1, (48 << 20) + 1, 1 << 40):
+            with pytest.raises(HifimethError):
+                m.set_option("group_bases", bad)
+        m.set_option("group_bases", 48 << 20)
+        m.set_option("group_bases", 0)
+        reads = synth_reads(3, seed=5, median_len=2000, sigma=0.2)
+        assert len(m.call(reads)) > 100
+        assert 0 < m.timing()["group_bases"] <= 16 << 20
+
+
 @pytest.mark.parametrize("spec,tag", [("cpg", "cpg"), ("cpg,chg,chh", "all")])
 def test_config1_committed_goldens(spec, tag):
     """BASELINE.json configs[1]: CpG-only (and all-context) calls of a fixed read set against the COMMITTED CPU-path
