@@ -14,8 +14,15 @@ only the synthesis of the reads (the stand-in for BAM decode) happens before it.
 slabs (reads are independent: no data-path collective, weak scaling); `value` is the whole-job sites/s = sum of sites
 over ranks / max time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--workload arabidopsis|human_slice] [--no-extras] [--no-e2e] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--workload arabidopsis|human_slice] [--e2e-dist] [--no-extras] [--no-e2e] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment STARTS the N ranks itself (launch_ranks: fresh child processes
+through torch.distributed.run, started before this process has made any HIP / torch.cuda call; never an exec), one device per rank,
+RCCL for the barrier and the (sum of sites, max of time) reduction; rank 0 prints the one line with n_gpus = N.
+BASELINE.json configs[3] (30x human-size over 8 GPUs) is `python bench.py --gpus 8 --workload human_slice --e2e-dist`: every rank
+streams its eighth (64 steps = 11.8 Gbases), then the ranks hand the devices to `python -m hifimeth_amd.call_dist` (queue mode) over ONE
+BAM file, so that the host feed (N ranks inflating, parsing, deflating side by side) is measured too.
 """
 import argparse
 import json
@@ -211,6 +218,94 @@ def end_to_end(slabs, n_reads, ctx="cpg,chg,chh", extra_flags=(), cycles=2):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+TORCHRUN_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+                "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCHELASTIC_ERROR_FILE", "OMP_NUM_THREADS")
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def clean_env():
+    """This process's environment without what a torchrun parent put there (a nested launch must build its own world)."""
+    return {k: v for k, v in os.environ.items() if k not in TORCHRUN_ENV}
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: N ranks as fresh children of torch.distributed.run.  This process has made
+    no HIP call and makes none (the device count comes from the KFD sysfs topology): it waits and passes the children's exit
+    code on.  Fails loudly when the box has fewer devices than ranks, unless HM_DIST_BACKEND=gloo asks for
+    the rehearsal in which the ranks share a card (RCCL refuses two ranks on one device)."""
+    import subprocess
+    from hifimeth_amd.dist import gpu_count
+    ndev = gpu_count()   # KFD sysfs, not HIP: this process does not open the device
+    if ndev < n and os.environ.get("HM_DIST_BACKEND", "nccl") != "gloo":
+        sys.exit(f"bench.py: --gpus {n} but this box has {ndev} GPU(s); one rank per device (RCCL).  "
+                 f"HM_DIST_BACKEND=gloo rehearses the multi-rank path with ranks sharing a device.")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] starting {n} ranks: {' '.join(cmd[1:9])} bench.py ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=clean_env())
+
+
+def end_to_end_dist(slabs, n_reads, ranks, cycles=2, ctx="cpg,chg,chh"):
+    """BASELINE.json configs[3]'s host side: ONE BAM file called by `ranks` processes that pull parts of it from the shared work
+    queue (python -m hifimeth_amd.call_dist: hifimeth-hip call -Q queue -C parts -d gpu per rank, rank-0 merge) -- the reference's
+    reader queue (src/corelib/sam_batch.hpp:38-54) and ordered write (mod_main.cpp:330-362) stretched over processes.  Wall clock of the
+    whole launch: torchrun + N engine start-ups + N x (inflate, parse, stage, GPU, tags, deflate) + merge."""
+    import shutil
+    import subprocess
+    import tempfile
+    from hifimeth_amd.synth import write_unaligned_bam
+    from hifimeth_amd.dist import gpu_count
+    pool = [r for s in slabs for r in s]
+    n_reads = min(n_reads, cycles * len(pool))
+    reads = [pool[i % len(pool)] for i in range(n_reads)]
+    tmp = tempfile.mkdtemp(prefix="hm_e2ed_")
+    try:
+        src, dst = os.path.join(tmp, "in.bam"), os.path.join(tmp, "out.bam")
+        t0 = time.perf_counter()
+        write_unaligned_bam(src, reads, level=1, threads=host_cores())
+        t_build = time.perf_counter() - t0
+        env = clean_env()
+        env.pop("HM_DIST_BACKEND", None)   # call_dist's ranks never touch the GPU themselves: gloo barrier, the native child owns the device
+        threads = max(1, host_cores() // ranks)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), "-m", "hifimeth_amd.call_dist", "-c", ctx, "-t", str(threads), src, dst]
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True, env=env, cwd=ROOT)
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            return {"error": f"exit {p.returncode}: {p.stderr[-400:]}"}
+        tot = {"CpG samples": 0, "CHG samples": 0, "CHH samples": 0, "Bases": 0, "Reads": 0}
+        per_rank, parts_taken = [], []
+        for line in p.stderr.splitlines():   # every rank's native child prints its own final stats
+            if "##" in line and ":" in line:
+                k, v = line.split("##", 1)[1].split(":", 1)
+                k, v = k.strip(), v.strip()
+                if k in tot:
+                    tot[k] += int(v)
+                elif k.startswith("Parts taken"):
+                    parts_taken.append(int(v.split()[0]))
+                elif k.startswith("Wall time"):
+                    per_rank.append(float(v.split()[0]))
+        sites = tot["CpG samples"] + tot["CHG samples"] + tot["CHH samples"]
+        return {"value": sites / wall, "unit": "sites/s", "wall_s": wall, "ranks": ranks, "devices": gpu_count(),
+                "reads": tot["Reads"], "reads_in_file": len(reads), "bases": tot["Bases"], "sites": sites,
+                "bam_in_MB": os.path.getsize(src) / 1e6, "bam_out_MB": os.path.getsize(dst) / 1e6,
+                "host_threads_per_rank": threads, "host_cores": host_cores(), "parts_taken_by_rank": parts_taken,
+                "rank_wall_s": per_rank, "bam_build_s": t_build,
+                "command": f"python -m torch.distributed.run --nproc-per-node {ranks} -m hifimeth_amd.call_dist -t {threads} IN.bam OUT.bam",
+                "note": "queue mode: parts of ~256 MB of BAM (at least 4 per rank) claimed from a flock'ed counter; whole launch incl. "
+                        "torchrun, every rank's engine start-up and the rank-0 merge; ranks beyond the box's devices share a card"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 WORKLOADS = {
     # BASELINE.json configs[2]: 30x Arabidopsis-size, GC 0.36, i.i.d. bases (SURVEY.md 8d); 20 steps of 11 700 reads cover it in full
     "arabidopsis": {"gc": 0.36, "cpg_oe": 1.0, "steps": 20, "total_sites": 1.1e9,
@@ -269,6 +364,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI run (BAM in -> BAM out, default flags)")
     ap.add_argument("--e2e-reads", type=int, default=96000, help="reads of the synthetic BAM of the end-to-end run (96000 ~ 5 GB: start-up amortised)")
     ap.add_argument("--e2e-cycles", type=int, default=2, help="how often the end-to-end file may repeat the read pool (4 with --e2e-reads 234000: configs[2] in full)")
+    ap.add_argument("--e2e-dist", action="store_true",
+                    help="after the timed region: ONE BAM file called by all ranks through the shared work queue (python -m hifimeth_amd.call_dist)")
+    ap.add_argument("--e2e-dist-ranks", type=int, default=0, help="ranks of the --e2e-dist leg (default: --gpus; more ranks than devices share a card)")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
                     help="CNN arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (e.g. front_waves=8)")
@@ -277,12 +375,24 @@ def main():
     if args.steps is None:
         args.steps = wl["steps"]
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process only launches the N ranks (before anything here has touched the GPU) and waits
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     from hifimeth_amd import MethylationCaller
     from hifimeth_amd import dist as hmdist
 
     rank, local_rank, world = hmdist.env_world()
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}: one rank per GPU, start as many ranks as --gpus says")
     # HM_DIST_BACKEND=gloo lets the multi-rank path be rehearsed on a box with fewer GPUs than ranks
     backend = os.environ.get("HM_DIST_BACKEND", "nccl")
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < world and backend == "nccl":
+        sys.exit(f"bench.py: {world} ranks but {ndev} GPU(s) on this box: RCCL needs one device per rank (HM_DIST_BACKEND=gloo rehearses with a shared card)")
     # HM_BENCH_FORCE_DIST=1 builds a world of one, so that the RCCL barrier / reductions run on a one-GPU box too
     force = os.environ.get("HM_BENCH_FORCE_DIST", "0") == "1"
     dist = hmdist.init_process_group(backend, force=force) if (world > 1 or force) else None
@@ -293,8 +403,6 @@ def main():
     bases_slab = [sum(r.l_qseq for r in s if r.has_kinetics() and r.l_qseq >= 1000) for s in slabs]
     from hifimeth_amd.caller import ReadBlock
     blocks = [ReadBlock(s) for s in slabs]
-    import torch
-    ndev = torch.cuda.device_count()
     mc = MethylationCaller(device=local_rank % max(ndev, 1), timing=True)
     mc.set_option("precision", args.precision)
     mc.stage_threads = max(1, min(8, host_cores() // max(1, min(world, 8)) // 2))
@@ -332,6 +440,9 @@ def main():
     sites_job = sum(sites_ctx)
     bases_job = sum(bases_slab[i] for i in order_t)
     sites_all, dt_max = hmdist.job_throughput(dist, sites_job, dt, device="cuda" if on_gpu_collectives else "cpu")
+    # every rank's own (sites, seconds, device index), on every rank: the line shows the slowest rank, not only the sum
+    by_rank = hmdist.gather_rank_stats(dist, [sites_job, dt, local_rank % max(ndev, 1), sum(tm["trunk_ms"]), sum(tm["edge_ms"]), sum(tm["tail_ms"])],
+                                       device="cuda" if on_gpu_collectives else "cpu")
 
     extras = {}
     if keep is not None and not streamed:
@@ -506,7 +617,13 @@ def main():
                        "fraction_of_configs2": sites_all / CONFIG2_SITES if args.workload == "arabidopsis" else None,
                        "fraction_of_configs3_rank_slice": bases_job / 11.6e9 if args.workload == "human_slice" else None,
                        "sites_by_context": {"CpG": sites_ctx[0], "CHG": sites_ctx[1], "CHH": sites_ctx[2]},
-                       "parallelism": f"read-sharded x{world}, no collective"},
+                       "parallelism": f"read-sharded x{world}, no collective",
+                       "launch": ("one process per GPU via torch.distributed.run (bench.py --gpus N starts the ranks itself when no torchrun "
+                                  "environment is present)" if world > 1 else "single process")},
+            "ranks": {"world": world, "backend": (backend if dist is not None else None), "rccl_ranks": world if on_gpu_collectives else 0,
+                      "sites_per_s": [r[0] / r[1] for r in by_rank], "seconds": [r[1] for r in by_rank], "device": [int(r[2]) for r in by_rank],
+                      "device_ms": [{"trunk_ms": r[3], "edge_ms": r[4], "tail_ms": r[5]} for r in by_rank],
+                      "slowest_over_mean_seconds": max(r[1] for r in by_rank) / (sum(r[1] for r in by_rank) / len(by_rank))},
             "roofline": roof,
             "device_ms_timed_region": gpu_ms,
             "effective_tflops_all_layers": sum(2.0 * MAC_TOTAL[c] * sites_ctx[c] for c in range(3)) / dt_max / 1e12,
@@ -526,7 +643,22 @@ def main():
             # CPU threads" for 30x Arabidopsis, ~1.1e9 sites => ~1.5e5 sites/s; the north-star asks for >= 30x of it
             out["readme_derived_48_thread_baseline"] = {"value": 1.5e5, "unit": "sites/s", "label": "derived, not measured",
                                                         "ratio": out["value"] / 1.5e5}
-        print(json.dumps(out))
+    # ---- the host feed of configs[3]: one BAM, all ranks pulling parts from the work queue.  Every rank frees its device first; the
+    # other ranks wait at the barrier (no timeout on the wait itself: the leg is bounded by the file, ~10 s per 5 GB and rank)
+    if args.e2e_dist:
+        mc.close()
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            try:
+                out["end_to_end_dist"] = end_to_end_dist(slabs, args.e2e_reads * (2 if world >= 4 else 1), args.e2e_dist_ranks or world,
+                                                         cycles=max(args.e2e_cycles, 3))
+            except Exception as ex:  # noqa: BLE001  (a failed extra leg must not void the line)
+                out["end_to_end_dist"] = {"error": repr(ex)}
+        if dist is not None:
+            dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     mc.close()
     if dist is not None:
         dist.destroy_process_group()

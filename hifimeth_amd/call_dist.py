@@ -30,6 +30,18 @@ CLI = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "hifimeth-
 PART_BYTES = 256 << 20
 
 
+def host_cores() -> int:
+    """CPUs this process may use: affinity mask capped by the cgroup CPU quota (what the native front end's own -t default counts)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def n_parts(path: str, world: int) -> int:
     """Parts of the queue: one per 256 MB of BAM, at least four per rank (every rank computes the same number)."""
     try:
@@ -67,13 +79,12 @@ def run(argv, backend: str | None = None) -> int:
         if copy:
             cmd = [CLI, "bamcopy"] + shard + argv[-2:]
         else:
-            ndev = 1
-            try:
-                import torch
-                ndev = max(torch.cuda.device_count(), 1)   # counting devices does not initialise the GPU
-            except Exception:  # noqa: BLE001
-                pass
-            cmd = [CLI, "call"] + argv[:-2] + shard + ["-d", str(local_rank % ndev)] + argv[-2:]
+            ndev = max(D.gpu_count(), 1)   # KFD sysfs: this rank never opens the device, its native child owns it
+            opts = argv[:-2]
+            if "-t" not in opts and world > 1:
+                # the ranks of a node share its cores: each native child gets its share (the CLI's own default is every core it may use)
+                opts = opts + ["-t", str(max(1, host_cores() // world))]
+            cmd = [CLI, "call"] + opts + shard + ["-d", str(local_rank % ndev)] + argv[-2:]
         try:
             rc = subprocess.call(cmd)
         except OSError as ex:   # e.g. the native front end is missing: every rank must still reach the collective below

@@ -19,6 +19,39 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def gpu_count_no_init() -> int:
+    """GPUs this process would see, counted WITHOUT opening the device (a launcher or a barrier-only rank must not become one more
+    process holding the GPU): KFD topology nodes with SIMDs, cut down by *_VISIBLE_DEVICES.  -1 = cannot tell (no KFD sysfs)."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return -1
+
+    for path in nodes:
+        try:
+            for line in open(path):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            return -1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def gpu_count() -> int:
+    """gpu_count_no_init(), or torch's count where the KFD topology cannot be read."""
+    n = gpu_count_no_init()
+    if n < 0:
+        import torch
+        n = torch.cuda.device_count()
+    return n
+
+
 def init_process_group(backend: str | None = None, force: bool = False):
     """Initialise torch.distributed from the env (MASTER_ADDR/PORT, RANK, WORLD_SIZE). Returns the
     module, or None for a single-process run (`force`: build a world of one anyway, to rehearse the collectives)."""
@@ -61,6 +94,17 @@ def job_throughput(dist, sites_local: float, seconds_local: float, device: str =
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(s.item()), float(t.item())
+
+
+def gather_rank_stats(dist, values: Sequence[float], device: str = "cpu") -> List[List[float]]:
+    """Every rank's row of floats, on every rank (all_gather): [rank][value]."""
+    if dist is None:
+        return [[float(v) for v in values]]
+    import torch
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    rows = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(rows, mine)
+    return [[float(x) for x in r.cpu()] for r in rows]
 
 
 def gather_calls(dist, per_slab_calls: Sequence[np.ndarray], slab_ids: Sequence[int], n_slabs: int, dtype):

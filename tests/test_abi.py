@@ -143,3 +143,16 @@ def test_trunk_mask_for_reads_is_a_host_function_of_the_sample():
     assert trunk_mask_for_reads(poor) == 4 and trunk_mask_for_reads(poor, 3) == 0   # (0.055)^2 = 0.3 % CpG; CHH ~ 9 %
     assert trunk_mask_for_reads(ReadBlock([])) == 0
     assert trunk_mask_for_reads(poor) == trunk_mask_for_reads(ReadBlock(poor.reads))
+
+
+def test_bench_gpus_flag_launches_or_fails_loudly():
+    """`python bench.py --gpus N` is never silently a one-rank run: without N devices (this container has none) and
+    without HM_DIST_BACKEND=gloo it exits non-zero BEFORE anything touches the GPU, and says why"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "HM_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 8:
+        assert r.returncode != 0 and "--gpus 8" in r.stderr and "{" not in r.stdout

@@ -86,3 +86,37 @@ def test_bench_two_ranks_launched_like_the_driver():
     # two different read sets (seed + rank): about twice the sites of one rank
     job_sites = d["value"] * d["ms_per_step"] * 1e-3
     assert 1.5 < job_sites / one["config"]["sites_per_gpu_step"] < 2.5 and job_sites != 2 * one["config"]["sites_per_gpu_step"]
+
+
+def _plain_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HM_DIST_BACKEND"] = "gloo"
+    return env
+
+
+def test_bench_starts_its_own_ranks():
+    """plain `python bench.py --gpus 2` (no torchrun, no WORLD_SIZE): the process launches two ranks itself and rank 0 prints the
+    whole-job line with n_gpus = 2 (gloo here: the two ranks share this box's one card)"""
+    d = _line([sys.executable, BENCH, "--gpus", "2", "--no-cpu-baseline"] + SMALL, env=_plain_env(), timeout=900)
+    _check_common(d, 2)
+    rk = d["ranks"]
+    assert rk["world"] == 2 and rk["backend"] == "gloo" and rk["rccl_ranks"] == 0 and len(rk["sites_per_s"]) == 2 and min(rk["sites_per_s"]) > 0
+    assert abs(max(rk["seconds"]) - d["ms_per_step"] * 2e-3) < 1e-6
+    assert "torch.distributed.run" in d["config"]["launch"]
+
+
+def test_bench_e2e_dist_leg_calls_one_bam_with_queue_ranks():
+    """`--e2e-dist`: after the timed region ONE BAM file is called by queue-mode ranks (python -m hifimeth_amd.call_dist), here two
+    ranks sharing the one card behind a single bench process (the box allows six processes on its GPU)"""
+    d = _line([sys.executable, BENCH, "--no-cpu-baseline", "--no-extras", "--e2e-dist", "--e2e-dist-ranks", "2", "--e2e-reads", "48"] + SMALL,
+              env=_plain_env(), timeout=900)
+    _check_common(d, 1)
+    e = d["end_to_end_dist"]
+    assert "error" not in e, e
+    assert e["ranks"] == 2 and e["reads_in_file"] == 48 and e["sites"] > 50000 and sum(e["parts_taken_by_rank"]) == 8 and e["value"] > 0
+
+
+def test_bench_refuses_a_world_that_contradicts_gpus():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1"] + SMALL, capture_output=True, text=True, cwd=ROOT, timeout=300,
+                       env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())))
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
