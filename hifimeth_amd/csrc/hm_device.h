@@ -130,5 +130,6 @@ struct CtxWeights {
 constexpr int C4_LEN = 25, C4_CH = 96;          // conv4 output = hand-off between front and tail kernels
 constexpr int ACT4_FLOATS = C4_LEN * C4_CH;      // 2400 floats / site
 constexpr int TAIL_SITES = 8;                    // sites stacked along M in the tail kernel
+constexpr int TAILP_STRIP = 144;                 // strip tail (hm_tail_p.hip): lattice rows (16 map rows apart) of E4 a pass of 16 sites shares in LDS
 
 }  // namespace hm

@@ -167,6 +167,8 @@ struct hm_engine {
     int edge_impl = 1;   // dense-trunk path, precision 1: 1 = edge2_kernel (hm_edge2.hip), 0 = edge_kernel (hm_trunk.hip); bit-identical
     // dense-trunk path, precision 1: 2 = the split tail (hm_tail_s.hip: conv5 + conv6, then conv7 .. softmax batched over 16 sites),
     // 1 = one kernel with resident weights (hm_tail_r.hip), 0 = tail_kernel_h (streams them per pass); bit-identical
+    // 3 = the strip tail (hm_tail_p.hip) for CHH -- 16 sites of one residue class per pass sharing a strip of E4 rows in LDS -- and
+    // tail_kernel_r for the sparse contexts
     int tail_impl = 1;
     int64_t tail_slice = int64_t(1) << 21;  // sites per launch pair of the split tail: its hand-off buffer holds 7.5 KB per site
     // trunk = 2 is decided ONCE per engine, from the reads of the first non-empty batch that is queued (counted on the
@@ -196,6 +198,7 @@ struct hm_engine {
     DevBuf d_act4, d_win, d_dbg, d_stamps;
     DevBuf d_map[3], d_e4, d_edge4, d_e4row, d_zeros, d_rowlist;  // dense trunk: maps of one read group, edge rows of its sites
     DevBuf d_x6;                // split tail: conv6's rows of one launch (hm_tail_s.hip)
+    DevBuf d_mark, d_ccnt, d_order, d_okey;  // strip tail (hm_tail_p.hip): per-map-row marks, class counters, the class-sorted site order and its keys
     DevBuf d_dump;              // sliding-window trunk: where a warm-up step's conv4 rows go (hm_trunk3.hip)
     int64_t x6_sites = 0;       // the site count d_x6's plane stride was laid out for
 
@@ -207,7 +210,7 @@ namespace {
 
 // Device bytes per base of a read group: E1..E3 maps (2 views x 512 B each), E4 (2 x 384 B), the sites' edge rows (768 B) and map-row
 // numbers, row lists -- times the 25 % head-room DevBuf::reserve adds.
-constexpr int64_t GROUP_BYTES_PER_BASE = (3 * 2 * 512 + 2 * 384 + 768 + 4 + 8) * 5 / 4;
+constexpr int64_t GROUP_BYTES_PER_BASE = (3 * 2 * 512 + 2 * 384 + 768 + 4 + 8 + 2 * 4 + 8) * 5 / 4;  // (+ the strip tail's marks per map row and its sorted order)
 
 int64_t effective_group_bases(hm_engine* e) {
     if (e->group_bases > 0) return e->group_bases;
@@ -658,7 +661,16 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
                                           e->d_e4row.as<int32_t>() + off, e->d_x6.as<uint16_t>(), ph, b->d_logits.as<float>(),
                                           b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu);
                     }
-                } else if (e->tail_impl == 1 && e->precision == 1)
+                } else if (e->tail_impl == 3 && e->precision == 1 && c == CHH) {
+                    const int64_t vrows = g.rows * n_views;
+                    e->d_mark.reserve(tail_strip_mark_bytes(vrows));
+                    e->d_ccnt.reserve(tail_strip_count_bytes(vrows));
+                    e->d_order.reserve((size_t)max_bases * sizeof(int32_t));
+                    e->d_okey.reserve((size_t)max_bases * sizeof(int32_t));
+                    launch_tail_strip(e->stream, sr, dm.w, maps, n_views, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(), e->d_mark.as<int32_t>(),
+                                      e->d_ccnt.as<int32_t>(), e->d_order.as<int32_t>(), e->d_okey.as<int32_t>(), b->d_logits.as<float>(),
+                                      b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu);
+                } else if ((e->tail_impl == 1 || e->tail_impl == 3) && e->precision == 1)
                     launch_tail_gather_r(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
                                          b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu);
                 else
@@ -877,7 +889,7 @@ void hm_destroy(hm_engine_t* e) {
     e->slots.clear();
     for (auto& m : e->model) m.params.release();
     for (DevBuf* b : {&e->d_act4, &e->d_win, &e->d_dbg, &e->d_stamps, &e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4, &e->d_rowlist,
-                      &e->d_edge4, &e->d_e4row, &e->d_zeros, &e->d_x6, &e->d_dump})
+                      &e->d_edge4, &e->d_e4row, &e->d_zeros, &e->d_x6, &e->d_dump, &e->d_mark, &e->d_ccnt, &e->d_order, &e->d_okey})
         b->release();
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -934,7 +946,7 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
         if (value < 0 || value > 1) return fail(e, HM_EINVAL, "edge_impl must be 0 or 1");
         e->edge_impl = (int)value;
     } else if (k == "tail_impl") {
-        if (value < 0 || value > 2) return fail(e, HM_EINVAL, "tail_impl must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(e, HM_EINVAL, "tail_impl must be 0, 1, 2 or 3");
         e->tail_impl = (int)value;
     } else if (k == "tail_slice") {
         if (value < 16) return fail(e, HM_EINVAL, "tail_slice must be at least 16");
@@ -1392,7 +1404,7 @@ int hm_get_timing(hm_engine_t* e, hm_timing_t* t) {
     *t = e->acc;
     t->group_bases = effective_group_bases(e);  // (sized from free device memory now if no read has been staged yet)
     t->group_bytes = 0;
-    for (const DevBuf* d : {&e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4, &e->d_rowlist, &e->d_edge4, &e->d_e4row, &e->d_x6, &e->d_dump})
+    for (const DevBuf* d : {&e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4, &e->d_rowlist, &e->d_edge4, &e->d_e4row, &e->d_x6, &e->d_dump, &e->d_mark, &e->d_ccnt, &e->d_order, &e->d_okey})
         t->group_bytes += (int64_t)d->cap;
     return HM_OK;
 }

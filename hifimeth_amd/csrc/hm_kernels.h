@@ -86,6 +86,14 @@ size_t tail_split_x6_plane_halves(int64_t sites);
 size_t tail_split_x6_bytes(int64_t sites);
 void launch_tail_split(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
                        const int32_t* e4row, uint16_t* x6, size_t x6_plane_halves, float* logits, float* p, uint8_t* ml, int grid);
+// the STRIP tail (hm_tail_p.hip) for a dense context (CHH): the launch's sites visited in (first map row mod 16, first map row) order,
+// 16 sites of one residue class per pass sharing one strip of TAILP_STRIP lattice rows in LDS; bit-identical results.
+// `mark`: tail_strip_mark_bytes(view rows x views), `cnt`: tail_strip_count_bytes(same), `order` / `okey`: one int32 per site of the launch.
+size_t tail_strip_mark_bytes(int64_t map_rows);
+size_t tail_strip_count_bytes(int64_t map_rows);
+void launch_tail_strip(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, int n_views, const uint16_t* edge4,
+                       const int32_t* e4row, int32_t* mark, int32_t* cnt, int32_t* order, int32_t* okey, float* logits, float* p, uint8_t* ml,
+                       int grid);
 void launch_trunk2(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,
                    const TrunkMaps& maps, int grid, bool w16, bool waves8 = false);

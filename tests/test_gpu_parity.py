@@ -695,6 +695,34 @@ def test_resident_tail_is_byte_identical_to_the_streaming_tail():
 
 
 @pytest.mark.gpu
+def test_strip_tail_is_byte_identical_to_the_resident_tail():
+    """Engine option tail_impl = 3: CHH's sites are visited in (first E4 map row mod 16, map row) order and a pass takes up to 16
+    consecutive sites of one residue class that share one strip of 144 lattice rows in LDS (hm_tail_p.hip; hm_convp.h: the sites along
+    the rows of the MFMA tiles, zero-padding taps skipped).  Every accumulator keeps its order of products, so the calls are
+    byte-identical to tail_kernel_r's (and tail_kernel_h's) -- for one read, many reads, homopolymers (no CHH site at all / one every
+    position), wide kinetics, reads stored reversed, trunk groups cut inside the slab, a second batch through the same engine, and grids
+    of 1 / 7 / 256 workgroups (a workgroup's range of the sorted list cuts passes at arbitrary places)."""
+    from hifimeth_amd import MethylationCaller
+    reads = _mixed_reads() + synth_reads(12, seed=178, median_len=7000, sigma=0.5, frac_wide=0.3)
+    cases = [("cpg,chg,chh", reads, None, None), ("chh", reads[:1], None, None), ("chh", reads, 32768, None), ("chh", reads, None, 1),
+             ("chh", reads, 65536, 7)]
+    for spec, rs, group_bases, ncu in cases:
+        out = []
+        for impl in (1, 3):
+            with MethylationCaller(contexts=spec, device=0, timing=True) as m:
+                m.set_option("trunk", 1)
+                m.set_option("tail_impl", impl)
+                if group_bases:
+                    m.set_option("group_bases", group_bases)
+                if ncu:
+                    m.set_option("num_cu", ncu)
+                out.append(m.call(rs).copy())
+                out.append(m.call(rs[::-1]).copy())      # a second, different batch through the same engine (buffers reused)
+        assert len(out[0]) == len(out[2]) > 50, (spec, len(out[0]))
+        assert out[0].tobytes() == out[2].tobytes() and out[1].tobytes() == out[3].tobytes(), (spec, group_bases, ncu)
+
+
+@pytest.mark.gpu
 def test_human_like_reads_mix_the_per_site_and_the_trunk_path_in_one_engine(oracle, oracle_models):
     """BASELINE.json configs[3] statistics (bench.py --workload human_slice: GC 0.41, CpG depleted to observed / expected 0.24 -> ~1 %
     of the bases): with the default options CpG takes the per-site kernels while CHG and CHH take the dense trunk, in the same engine
