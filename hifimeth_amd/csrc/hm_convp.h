@@ -54,14 +54,15 @@ struct EpiP {
         *reinterpret_cast<half4*>(lo + TILE * 16 * ORS + col) = s.l;
     }
 };
-// fc1: ReLU, fp32 h[site][HRS] for the VALU fc2; `out` is this lane's: h + li * HRS + 4 * lk
+// fc1: ReLU, fp32 h[site][8 parts of 32, HPS floats apart] for the VALU fc2; `out` is this lane's: h + li * (8 HPS) + 4 * lk
+template <int HPS>
 struct EpiFc1P {
     static constexpr int NV0 = 4, NV1 = 1, NW = 1, WMASK = 0x200;
     struct St { float4 v; };
     float* out;
     __device__ __forceinline__ void s0(const f32x4& acc, St& s) const { s.v = make_float4(relu1(acc[0]), relu1(acc[1]), relu1(acc[2]), relu1(acc[3])); }
     template <int TILE>
-    __device__ __forceinline__ void s1(int col, const St& s) const { *reinterpret_cast<float4*>(out + col) = s.v; }
+    __device__ __forceinline__ void s1(int col, const St& s) const { *reinterpret_cast<float4*>(out + col + (col >> 5) * (HPS - 32)) = s.v; }
 };
 
 // The stream: groups of tiles (hm_convt.h's TG) run back to back as (group, k-block) blocks; per block the MFMAs of the tiles that
@@ -107,7 +108,13 @@ struct PConv {
         const int lk = (tid & 63) >> 4;
         f32x4 acc[2][AMAX];
         half8 x[NS];
-        typename Epi::St est[AMAX];
+        // this lane's biases, once per call (read per group, the LDS read and its wait stood in front of every group's first MFMA)
+        float4 bz[WT::NTR];
+#pragma unroll
+        for (int j = 0; j < WT::NTR; ++j) {
+            if constexpr (std::is_pointer_v<Bias>) bz[j] = *reinterpret_cast<const float4*>(bias + ncol[j] + 4 * lk);
+            else bz[j] = bias(j);
+        }
 
         auto reads = [&](auto b_) __attribute__((always_inline)) {
             constexpr int b = decltype(b_)::value, g = b / KB, kb = b % KB, s0 = slot_base(b);
@@ -122,12 +129,15 @@ struct PConv {
                 }
             });
         };
-        auto stage = [&](auto g_, auto a_, auto s_) __attribute__((always_inline)) {
-            constexpr int g = decltype(g_)::value, a = decltype(a_)::value, st = decltype(s_)::value;
+        // an accumulator's epilogue: compute (ReLU, split) and store back to back -- in this layout it is 7 vector instructions and two
+        // LDS stores with an immediate address, so that one k-block hides it; nothing is staged across blocks (12 registers fewer)
+        auto stage = [&](auto g_, auto a_) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_)::value, a = decltype(a_)::value;
             using G = Grp<g>;
             constexpr int ti = G::acc_tile(a), tile = G::tile(ti), j = G::acc_j(a);
-            if constexpr (st == 0) epi.s0(acc[g & 1][a], est[a]);
-            else epi.template s1<tile>(ncol[j], est[a]);
+            typename Epi::St est;
+            epi.s0(acc[g & 1][a], est);
+            epi.template s1<tile>(ncol[j], est);
         };
         tstatic_for<0, issued(0)>(reads);
 
@@ -135,13 +145,6 @@ struct PConv {
             constexpr int c = decltype(c_)::value, g = c / KB, kb = c % KB, s0 = slot_base(c);
             using G = Grp<g>;
             if constexpr (kb == 0) {
-                float4 bz[WT::NTR];
-                constexpr int NBZ = G::GP > 0 ? G::NJ : 1;
-#pragma unroll
-                for (int j = 0; j < NBZ; ++j) {
-                    if constexpr (std::is_pointer_v<Bias>) bz[j] = *reinterpret_cast<const float4*>(bias + ncol[j] + 4 * lk);
-                    else bz[j] = bias(j);
-                }
                 tstatic_for<0, G::NA>([&](auto a_) __attribute__((always_inline)) {
                     constexpr int a = decltype(a_)::value, j = G::acc_j(a);
                     acc[g & 1][a] = f32x4{bz[j].x, bz[j].y, bz[j].z, bz[j].w};
@@ -160,20 +163,19 @@ struct PConv {
                 });
             });
             // the previous group's accumulators leave between this group's MFMAs: 2 stages each, dealt over its k-blocks
-            constexpr int NAP = g > 0 ? nas[g > 0 ? g - 1 : 0] : 0, NST = 2 * NAP;
-            constexpr int E0 = kb * NST / KB, E1 = (kb + 1) * NST / KB;
+            constexpr int NAP = g > 0 ? nas[g > 0 ? g - 1 : 0] : 0;
+            constexpr int E0 = kb * NAP / KB, E1 = (kb + 1) * NAP / KB;
             if constexpr (g > 0)
                 tstatic_for<E0, E1>([&](auto e_) __attribute__((always_inline)) {
-                    constexpr int e = decltype(e_)::value;
-                    stage(std::integral_constant<int, (g > 0 ? g - 1 : 0)>{}, std::integral_constant<int, e / 2>{}, std::integral_constant<int, e % 2>{});
+                    stage(std::integral_constant<int, (g > 0 ? g - 1 : 0)>{}, e_);
                 });
             hook(c_);
             {
                 constexpr int NRD = [&]() constexpr { int n = 0; for (int b = (c > 0 ? P0 : P1); b < P1; ++b) n += nreads(b); return n; }();
-                constexpr int ND = NRD + (kb == 0 && std::is_pointer_v<Bias> ? (G::GP > 0 ? G::NJ : 1) : 0) + HDS;
+                constexpr int ND = NRD + HDS;
                 constexpr int NM = nmfma(c);
-                constexpr int NV = [&]() constexpr { int n = 0; for (int e = E0; e < E1; ++e) n += e % 2 == 0 ? Epi::NV0 : Epi::NV1; return g > 0 ? n : 0; }();
-                constexpr int NWR = [&]() constexpr { int n = 0; for (int e = E0; e < E1; ++e) n += e % 2 == 1 ? Epi::NW : 0; return g > 0 ? n : 0; }();
+                constexpr int NV = g > 0 ? (E1 - E0) * (Epi::NV0 + Epi::NV1) : 0;
+                constexpr int NWR = g > 0 ? (E1 - E0) * Epi::NW : 0;
                 tstatic_for<0, NM>([&](auto q_) __attribute__((always_inline)) {
                     constexpr int q = decltype(q_)::value;
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -185,8 +187,7 @@ struct PConv {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        tstatic_for<0, nas[NG - 1]>([&](auto a_) __attribute__((always_inline)) { stage(std::integral_constant<int, NG - 1>{}, a_, std::integral_constant<int, 0>{}); });
-        tstatic_for<0, nas[NG - 1]>([&](auto a_) __attribute__((always_inline)) { stage(std::integral_constant<int, NG - 1>{}, a_, std::integral_constant<int, 1>{}); });
+        tstatic_for<0, nas[NG - 1]>([&](auto a_) __attribute__((always_inline)) { stage(std::integral_constant<int, NG - 1>{}, a_); });
     }
 };
 

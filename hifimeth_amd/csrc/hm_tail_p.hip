@@ -47,7 +47,10 @@ namespace {
 struct PGeo {
     static constexpr int S = 16, NW = 4;
     static constexpr int L4 = C4_LEN, L5 = 13, L6 = 7, L7 = 4, L8 = 2;
-    static constexpr int RS = 104, RS64 = 72, HRS = 260;   // halves, halves, floats
+    static constexpr int RS = 104, RS64 = 72;               // halves
+    // fc1's fp32 output for the VALU fc2: a site's 256 values in 8 parts of 32, parts 36 floats apart (fc2's 16 lanes of a site read 8 distinct
+    // parts: 144-byte steps fall into different banks), sites 288 apart; fc2's weights likewise, the two outputs 324 apart
+    static constexpr int HPS = 36, HRS = 8 * HPS, F2S = 324;
     static constexpr int R = TAILP_STRIP;                  // strip rows (lattice rows 16 map rows apart)
     static constexpr int SPAN = R - (L4 - 2);              // a pass's sites start at most this many lattice rows apart (0 .. SPAN)
     // plane A (halves from the plane pointer)
@@ -57,7 +60,7 @@ struct PGeo {
     static constexpr int C7 = 0, C8 = L7 * S * RS64, HFC = C8 + L8 * S * RS64;   // conv7's / conv8's planes, fc1's fp32 output, inside B's hi | lo plane
     static constexpr int LDS_HALVES = 2 * PA + 2 * P5;
     static_assert(L6 * S * RS <= R * RS, "conv6's output overlays the strip");
-    static_assert(HFC * 2 % 16 == 0 && HFC + S * HRS * 2 <= 2 * P5, "fc1's output fits behind conv8's");
+    static_assert(HFC * 2 % 16 == 0 && HFC + S * HRS * 2 <= P5, "fc1's output fits behind conv8's, inside the hi plane");
     static constexpr int LATE_ROWS = L6 * S;               // strip rows conv6's output overlays: fetched once conv7 has read it
     static constexpr int QROWS = 4, QBYTES = QROWS * RS * 2, NQ = R / QROWS, LATEQ = LATE_ROWS / QROWS;
     static_assert(R % QROWS == 0 && LATE_ROWS % QROWS == 0 && RS * 2 == 13 * 16, "row-aligned pieces of 13 sixteen-byte units");
@@ -97,7 +100,7 @@ void tail_kernel_p(SiteRange sr, CtxWeights W, float* __restrict__ logits, float
     if (i_begin >= i_end) return;
 
     __shared__ __attribute__((aligned(16))) half_t smem[T::LDS_HALVES];
-    __shared__ __attribute__((aligned(16))) float fc2w[2 * 256 + 4];          // fc2 weights + bias
+    __shared__ __attribute__((aligned(16))) float fc2w[T::F2S + 8 * T::HPS + 4];  // fc2 weights (padded like fc1's output) + bias
     __shared__ __attribute__((aligned(16))) float bias_l[96 + 96 + 64 + 64];  // conv5 .. conv8 biases
     __shared__ uint32_t touch_dump[64];                                       // where the touch loads' dwords go (never read)
     half_t* a_hi = smem;
@@ -110,11 +113,14 @@ void tail_kernel_p(SiteRange sr, CtxWeights W, float* __restrict__ logits, float
     const float* b7 = bias_l + 192;
     const float* b8 = bias_l + 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < 2 * 256 + 2; i += NW * 64) fc2w[i] = i < 512 ? W.fc2_w[i] : W.fc2_b[i - 512];
+    for (int i = tid; i < 2 * 256 + 2; i += NW * 64) {
+        if (i < 512) fc2w[(i >> 8) * T::F2S + ((i & 255) >> 5) * T::HPS + (i & 31)] = W.fc2_w[i];
+        else fc2w[T::F2S + 8 * T::HPS + (i - 512)] = W.fc2_b[i - 512];
+    }
     for (int i = tid; i < 320; i += NW * 64) bias_l[i] = i < 96 ? W.bias[4][i] : i < 192 ? W.bias[5][i - 96] : i < 256 ? W.bias[6][i - 192] : W.bias[7][i - 256];
     auto wf = [&](int i) { return reinterpret_cast<const half_t*>(W.wfrag_h[i]); };
 
-    // ---- resident weights (as in tail_kernel_r): n-tiles (a, b) of conv5 and conv6, n-tile `wave` of conv7 -------------------------
+    // ---- resident weights: n-tiles (a, b) of conv5 and conv6 (as in tail_kernel_r); conv7's, conv8's and fc1's arrive per pass -------
     const int nta = wave == 0 ? 0 : wave == 1 ? 2 : wave == 2 ? 3 : 5, ntb = wave < 2 ? 1 : 4;
     const int nt56[2] = {nta, ntb}, col56[2] = {16 * nta, 16 * ntb};
     const int nt78[1] = {wave}, col78[1] = {16 * wave};
@@ -124,7 +130,6 @@ void tail_kernel_p(SiteRange sr, CtxWeights W, float* __restrict__ logits, float
     TW<6, 1> W8;
     tw_load(wf(4), nt56, lane, W5);
     tw_load(wf(5), nt56, lane, W6);
-    tw_load(wf(6), nt78, lane, W7);
 
     using C96 = PCfg<96, 3>;
     using C64 = PCfg<64, 3>;
@@ -313,11 +318,15 @@ void tail_kernel_p(SiteRange sr, CtxWeights W, float* __restrict__ logits, float
             if (odd) PConv<C96, I6, 8, 1, TG<4, 1, 0, 1>, TG<5, 1, 1, 1>, TG<6, 1, 2, 1>, TG<0, 0, 3, 1>>::run(b_hi, b_lo, W6, b6, col56, ia, e6, hook_early);
             else PConv<C96, I6, 8, 1, TG<0, 1, 4, 1>, TG<1, 1, 5, 1>, TG<2, 1, 6, 1>, TG<3, 1, 0, 0>>::run(b_hi, b_lo, W6, b6, col56, ia, e6, hook_early);
         }
+        // conv7's weights are NOT resident (the register file holds conv5's and conv6's, 288 registers per wave, and the working set; with
+        // conv7's 72 on top the allocator spills): requested here, behind conv6's last MFMA, they arrive in k order while the last epilogue,
+        // the barrier and conv7's first blocks run
+        tw_load(wf(6), nt78, tl & 63, W7);
         TTS(3);
         lds_barrier();
         TTS(4);
         // ---- conv7: strip's first rows -> B (conv7 plane) ----------------------------------------------------------------------------------
-        tw_load(wf(7), nt78, lane, W8);  // conv8's weights: requested a layer ahead
+        tw_load(wf(7), nt78, tl & 63, W8);  // conv8's weights: requested a layer ahead
         {
             const I7 ia{li * T::RS + 8 * lk};
             const EpiP<T::RS64> e7{b_hi + T::C7 + li * T::RS64 + 4 * lk, b_lo + T::C7 + li * T::RS64 + 4 * lk};
@@ -356,7 +365,7 @@ void tail_kernel_p(SiteRange sr, CtxWeights W, float* __restrict__ logits, float
         TTS(8);
         {
             const IF ia{li * T::RS64 + 8 * lk};
-            const EpiFc1P ef{hfc + li * T::HRS + 4 * lk};
+            const EpiFc1P<T::HPS> ef{hfc + li * T::HRS + 4 * lk};
             FC1::run(b_hi, b_lo, WF, [&](int j) __attribute__((always_inline)) { return bzf[j]; }, colf0, ia, ef);
             tw_load(wf(8), ntf1, tl & 63, WF);
             FC1::run(b_hi, b_lo, WF, [&](int j) __attribute__((always_inline)) { return bzf[2 + j]; }, colf1, ia, ef);
@@ -366,15 +375,15 @@ void tail_kernel_p(SiteRange sr, CtxWeights W, float* __restrict__ logits, float
         // fc2 + softmax (mod_batch.cpp:46-64) in fp32: 16 lanes per site = 2 outputs x 8 partial sums
         {
             const int bsite = tl >> 4, o = (tl >> 3) & 1, part = tl & 7;
-            const float* h = hfc + bsite * T::HRS + part * 32;
-            const float* w2 = fc2w + o * 256 + part * 32;
+            const float* h = hfc + bsite * T::HRS + part * T::HPS;
+            const float* w2 = fc2w + o * T::F2S + part * T::HPS;
             float sum = 0.f;
 #pragma unroll 8
             for (int k = 0; k < 32; ++k) sum = fmaf(h[k], w2[k], sum);
             sum += __shfl_xor(sum, 4, 64);
             sum += __shfl_xor(sum, 2, 64);
             sum += __shfl_xor(sum, 1, 64);
-            sum += fc2w[512 + o];
+            sum += fc2w[T::F2S + 8 * T::HPS + o];
             const float other = __shfl_xor(sum, 8, 64);
             if ((tl & 15) == 0 && bsite < cur.take) {
                 const float v0 = sum, v1 = other;
