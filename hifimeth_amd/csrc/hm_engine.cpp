@@ -167,9 +167,9 @@ struct hm_engine {
     int edge_impl = 1;   // dense-trunk path, precision 1: 1 = edge2_kernel (hm_edge2.hip), 0 = edge_kernel (hm_trunk.hip); bit-identical
     // dense-trunk path, precision 1: 2 = the split tail (hm_tail_s.hip: conv5 + conv6, then conv7 .. softmax batched over 16 sites),
     // 1 = one kernel with resident weights (hm_tail_r.hip), 0 = tail_kernel_h (streams them per pass); bit-identical
-    // 3 = the strip tail (hm_tail_p.hip) for CHH -- 16 sites of one residue class per pass sharing a strip of E4 rows in LDS -- and
-    // tail_kernel_r for the sparse contexts
-    int tail_impl = 1;
+    // 3 (default) = the strip tail (hm_tail_p.hip) for CHH -- 16 sites of one residue class per pass sharing a strip of E4 rows in LDS --
+    // and tail_kernel_r for the sparse contexts (their sites are too far apart to share rows)
+    int tail_impl = 3;
     int64_t tail_slice = int64_t(1) << 21;  // sites per launch pair of the split tail: its hand-off buffer holds 7.5 KB per site
     // trunk = 2 is decided ONCE per engine, from the reads of the first non-empty batch that is queued (counted on the
     // host, estimate_density): the choice must not depend on which batches happen to have finished when the next one is
