@@ -37,7 +37,10 @@ class hm_timing_t(C.Structure):
                 ("trunk_launches", C.c_int64 * 3), ("edge_launches", C.c_int64 * 3),
                 ("trunk_positions", C.c_int64 * 3),
                 ("trunk_list_steps", C.c_int64 * 3), ("trunk_const_steps", C.c_int64 * 3),
-                ("group_bases", C.c_int64), ("group_bytes", C.c_int64)]
+                ("group_bases", C.c_int64), ("group_bytes", C.c_int64), ("tail_strip_passes", C.c_int64)]
+
+
+HM_ABI_VERSION = 5   # include/hifimeth_hip.h
 
 
 def build(force: bool = False) -> str:
@@ -98,6 +101,8 @@ def lib():
         "hm_convert_model": (C.c_int, [cp, cp]),
         "hm_get_stamps": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
         "hm_get_timing": (C.c_int, [vp, C.POINTER(hm_timing_t)]),
+        "hm_abi_version": (C.c_int, []),
+        "hm_timing_size": (C.c_size_t, []),
         "hm_reset_timing": (C.c_int, [vp]),
         # pileup
         "hm_pileup_create": (C.c_int, [C.POINTER(vp), C.c_int]),
@@ -121,5 +126,9 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     L._hm_symbols = tuple(sig)
+    # a library built from another header would write past (or short of) the structs mirrored above
+    if L.hm_abi_version() != HM_ABI_VERSION or L.hm_timing_size() != C.sizeof(hm_timing_t):
+        raise ImportError(f"{LIB_PATH}: ABI {L.hm_abi_version()} / hm_timing_t {L.hm_timing_size()} bytes, this package expects "
+                          f"{HM_ABI_VERSION} / {C.sizeof(hm_timing_t)}: rebuild (python -c 'import __graft_entry__ as g; g.build()')")
     _lib = L
     return L

@@ -89,7 +89,8 @@ void usage() {
             "  -c <list>    contexts to call: cpg,chg,chh (default all)\n"
             "  -t <int>     host threads for BGZF inflate/deflate and tag building (default: all this process is granted)\n"
             "  -d <list>    GPU ordinals, e.g. 0,1,2,3 (default 0)\n"
-            "  -p <0|1>     arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default), 0 = fp32 MFMA\n"
+            "  -p <0|1|2>   arithmetic: 1 = split-half fp16x3 MFMA + fp32 accumulate (default, |dp| <= 1e-4), 0 = fp32 MFMA,\n"
+            "               2 = as 1 with plain fp16 weights in conv8 and fc1 (|dp| <= 1e-3)\n"
             "  -R <r/w>     this process is rank r of w: call only the r-th part of BAM (split by BGZF offset) and write\n"
             "               MOD-BAM.shard<r>; `%s merge MOD-BAM w` joins the shards in input order\n"
             "  -Q <file>    pull the parts of BAM from the counter in <file>, shared by all ranks of the job, instead of taking the\n"
@@ -215,7 +216,7 @@ bool parse(int argc, char** argv, Options& o) {
     o.out = argv[i + 1];
     if (o.model_dir.empty()) o.model_dir = exe_dir() + "/../weights";
     if (o.threads <= 0) o.threads = default_threads();
-    if (o.read_batch < 1 || o.min_read_size < 0 || o.level < 0 || o.level > 9 || o.precision < 0 || o.precision > 1) return false;
+    if (o.read_batch < 1 || o.min_read_size < 0 || o.level < 0 || o.level > 9 || o.precision < 0 || o.precision > 2) return false;
     if (o.slab_bases < 1 || o.trunk < -1 || o.trunk > 1 || o.chunks < 0) return false;
     return true;
 }
@@ -433,6 +434,11 @@ int cmd_call(int argc, char** argv) {
     // one engine per device, three batch slots each: one being staged, one on the GPU, one being tagged / written
     std::vector<hm_engine_t*> eng(o.devices.size(), nullptr);
     for (size_t d = 0; d < eng.size(); ++d) {
+        if (d == 0 && (hm_abi_version() != HM_ABI_VERSION || hm_timing_size() != sizeof(hm_timing_t))) {
+            fprintf(stderr, "[hifimeth-hip] libhifimeth_hip.so was built from another include/hifimeth_hip.h (ABI %d, this program %d)\n",
+                    hm_abi_version(), HM_ABI_VERSION);
+            return EXIT_FAILURE;
+        }
         if (hm_create(&eng[d], o.model_dir.c_str(), o.ctx_mask, o.devices[d]) < 0) {
             fprintf(stderr, "[%s] device %d: %s\n", kName, o.devices[d], hm_last_error(nullptr));
             return EXIT_FAILURE;
@@ -656,6 +662,9 @@ int cmd_call(int argc, char** argv) {
     static const char* cn[3] = {"CpG", "CHG", "CHH"};
     for (int c = 0; c < 3; ++c)
         if (all_ctx[c]) fprintf(stderr, "  ## %s samples: %zu\n", cn[c], all_ctx[c]);
+    // which library produced / consumed the compressed bytes (-Z falls back to zlib silently where libdeflate is missing)
+    fprintf(stderr, "  ## BGZF codec: inflate %s, deflate %s\n", bam_have_libdeflate() ? "libdeflate" : "zlib",
+            o.ld_out && bam_have_libdeflate() ? "libdeflate" : o.ld_out ? "zlib (-Z asked, libdeflate not available)" : "zlib");
     if (!o.queue.empty()) fprintf(stderr, "  ## Parts taken from the queue: %zu of %d\n", all_parts, src.chunks);
     fprintf(stderr, "  ## Wall time: %.2f s (%.0f sites/s end to end)\n", sec, (double)(all_ctx[0] + all_ctx[1] + all_ctx[2]) / sec);
     return 0;

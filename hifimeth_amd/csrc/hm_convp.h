@@ -20,9 +20,12 @@
 namespace hm {
 
 // layer geometry: CIN channels per tap, KT taps
-template <int CIN_, int KT_>
+// (WLO = false: plain fp16 weights, the w_lo x_hi product dropped -- hm_convt.h's TCfg)
+template <int CIN_, int KT_, bool WLO_ = true>
 struct PCfg {
     static constexpr int CIN = CIN_, KT = KT_, KB = KT_ * CIN_ / 32;
+    static constexpr bool WLO = WLO_;
+    static constexpr int NPR = WLO_ ? 3 : 2;
     static_assert((KT_ * CIN_) % 32 == 0 && CIN_ % 32 == 0, "a k-block never straddles taps");
     static constexpr int tap(int kb) { return kb * 32 / CIN; }
     static constexpr int ch0(int kb) { return kb * 32 - tap(kb) * CIN; }
@@ -85,7 +88,7 @@ struct PConv {
     static constexpr bool skips(int g, int i, int kb) { return IA::skip(tile_of(g, i), kb); }
     static constexpr int nreads(int c) { int n = 0; for (int i = 0; i < nts[c / KB]; ++i) n += skips(c / KB, i, c % KB) ? 0 : 2; return n; }
     static constexpr int rslot(int c, int i) { int n = 0; for (int q = 0; q < i; ++q) n += skips(c / KB, q, c % KB) ? 0 : 2; return n; }
-    static constexpr int nmfma(int c) { int n = 0; for (int a = 0; a < nas[c / KB]; ++a) n += skips(c / KB, acc_tile_of(c / KB, a), c % KB) ? 0 : 3; return n; }
+    static constexpr int nmfma(int c) { int n = 0; for (int a = 0; a < nas[c / KB]; ++a) n += skips(c / KB, acc_tile_of(c / KB, a), c % KB) ? 0 : C::NPR; return n; }
     static constexpr int mfmas() { int n = 0; for (int c = 0; c < NB; ++c) n += nmfma(c); return n; }
     static constexpr int slot_base(int c) { int n = 0; for (int b = 0; b < c; ++b) n += nreads(b); return n % NS; }
     static constexpr int issued(int c) {
@@ -152,7 +155,7 @@ struct PConv {
             }
             constexpr int P0 = issued(c > 0 ? c - 1 : 0), P1 = issued(c);
             if constexpr (c > 0) tstatic_for<P0, P1>(reads);
-            tstatic_for<0, 3>([&](auto pr_) __attribute__((always_inline)) {
+            tstatic_for<0, C::NPR>([&](auto pr_) __attribute__((always_inline)) {
                 constexpr int pr = decltype(pr_)::value;
                 tstatic_for<0, G::NA>([&](auto a_) __attribute__((always_inline)) {
                     constexpr int a = decltype(a_)::value, i = G::acc_tile(a), j = G::acc_j(a), tile = G::tile(i);

@@ -26,9 +26,13 @@
 namespace hm {
 
 // layer geometry: CIN channels per tap, KT taps (stride-2 conv over a site's rows: taps one row apart), IRS halves per row
-template <int CIN_, int KT_, int IRS_>
+// WLO = false: the layer runs with plain fp16 WEIGHTS -- its w_lo x_hi product is dropped and the lo plane's fragments are not loaded
+// (engine option precision = 2, for the layers that hold BASELINE.json configs[4]'s bar: conv8 and fc1)
+template <int CIN_, int KT_, int IRS_, bool WLO_ = true>
 struct TCfg {
     static constexpr int CIN = CIN_, KT = KT_, IRS = IRS_;
+    static constexpr bool WLO = WLO_;
+    static constexpr int NPR = WLO_ ? 3 : 2;
     static constexpr int KB = KT * CIN / 32;
     static_assert((KT * CIN) % 32 == 0 && CIN % 32 == 0, "a k-block never straddles taps");
     // halves from a row's first element to this lane's 8 K elements of k-block kb
@@ -58,7 +62,7 @@ struct TW {
 };
 
 // fragments [n-tile][k-block][plane][lane] half8 of n-tiles nt[0..NTR) -> registers
-template <int KB, int NTR>
+template <bool LO = true, int KB, int NTR>
 __device__ __forceinline__ void tw_load(const half_t* __restrict__ wfrag, const int (&nt)[NTR], int lane, TW<KB, NTR>& W) {
     const half8* wp = reinterpret_cast<const half8*>(wfrag) + lane;
 #pragma unroll
@@ -66,7 +70,7 @@ __device__ __forceinline__ void tw_load(const half_t* __restrict__ wfrag, const 
 #pragma unroll
         for (int j = 0; j < NTR; ++j) {
             W.w[kb][j][0] = wp[(size_t)(nt[j] * KB + kb) * 128];
-            W.w[kb][j][1] = wp[(size_t)(nt[j] * KB + kb) * 128 + 64];
+            if constexpr (LO) W.w[kb][j][1] = wp[(size_t)(nt[j] * KB + kb) * 128 + 64];
         }
 }
 
@@ -122,7 +126,7 @@ struct TConv {
     static constexpr int tile_base(int g) { int t = 0; for (int i = 0; i < g; ++i) t += nts[i]; return t; }
     static constexpr int AMAX = amax(), TMAX = tmax(), NTILES = tile_base(NG);
     static_assert(NS >= 2 * TMAX, "the ring holds at least one block's operands");
-    static constexpr int mfmas() { int n = 0; for (int g = 0; g < NG; ++g) n += nas[g] * 3 * KB; return n; }
+    static constexpr int mfmas() { int n = 0; for (int g = 0; g < NG; ++g) n += nas[g] * C::NPR * KB; return n; }
     // ring bookkeeping, all at compile time
     static constexpr int nreads(int c) { return 2 * nts[c / KB]; }  // (hi, lo) per tile of block c
     static constexpr int slot_base(int c) { int n = 0; for (int b = 0; b < c; ++b) n += nreads(b); return n % NS; }
@@ -223,7 +227,7 @@ struct TConv {
             constexpr int P0 = issued(c > 0 ? c - 1 : 0), P1 = issued(c);
             if constexpr (c > 0) tstatic_for<P0, P1>(reads);
             // product-major over the group's accumulators: an accumulator is revisited NA MFMAs later
-            tstatic_for<0, 3>([&](auto pr_) __attribute__((always_inline)) {
+            tstatic_for<0, C::NPR>([&](auto pr_) __attribute__((always_inline)) {
                 constexpr int pr = decltype(pr_)::value;
                 tstatic_for<0, G::NA>([&](auto a_) __attribute__((always_inline)) {
                     constexpr int a = decltype(a_)::value, i = G::acc_tile(a), j = G::acc_j(a);
@@ -244,7 +248,7 @@ struct TConv {
                 // their LDS stores behind the last ones
                 constexpr int NRD = [&]() constexpr { int n = 0; for (int b = (c > 0 ? P0 : P1); b < P1; ++b) n += nreads(b); return n; }();
                 constexpr int ND = NRD + (kb == 0 && std::is_pointer_v<Bias> ? (G::GP > 0 ? G::NJ : 1) : 0) + HDS;
-                constexpr int NM = 3 * G::NA;
+                constexpr int NM = C::NPR * G::NA;
                 constexpr int NVA = kb == 0 && g + 1 < NG ? 9 * nts[g + 1 < NG ? g + 1 : 0] : 0;  // the next group's row offsets
                 constexpr int NV = NVA + [&]() constexpr { int n = 0; for (int e = E0; e < E1; ++e) n += e % 2 == 0 ? Epi::NV0 : Epi::NV1; return g > 0 ? n : 0; }();
                 constexpr int NWR = [&]() constexpr { int n = 0; for (int e = E0; e < E1; ++e) n += e % 2 == 1 ? Epi::NW : 0; return g > 0 ? n : 0; }();

@@ -153,7 +153,11 @@ struct hm_engine {
     // 0 = fp32 MFMA; 1 = split-half f16x3 MFMA with fp32 accumulate (default).  (Rounds 1-2 also had 2 / 3 = plain fp16 WEIGHTS in
     // conv6..conv8 / conv2..conv8 for BASELINE.json configs[4]: the literal configuration misses its 1e-3 bar -- 2.5e-3 -- and the
     // part that holds it bought nothing; closed in round 3, see README "configs[4]" and profiles/r02_term_error_table.txt.)
+    // 2 = as 1, with plain fp16 WEIGHTS (the w_lo x_hi product and the lo plane's fetches dropped) in conv8 and fc1: what of BASELINE.json
+    // configs[4] ("fp16 CNN weights, |dp| <= 1e-3") holds its bar with margin over multi-million-site sweeps (conv3 alone --
+    // 11 % of the trunk's MFMAs -- reaches 1.3e-3 over 6.1 M sites: diagnostic option conv3_w16, profiles/r05_parity_sweep_conv3_w16.txt)
     int precision = 1;
+    int conv3_w16 = 0;   // diagnostic: conv3 of the dense trunk with plain fp16 weights (measured above the 1e-3 bar; not part of any mode)
     int max_slots = 3;  // batch slots of the asynchronous API (the legacy calls use one more, slot 0)
     // conv1..conv4: 1 = once per read position (dense trunk, hm_trunk.hip), 0 = once per site (front kernels), 2 = per
     // context whichever is cheaper at the site density of the run's first batch: the trunk costs ~0.9 ns per base and strand
@@ -217,12 +221,17 @@ int64_t effective_group_bases(hm_engine* e) {
     if (const int64_t have = e->group_bases_eff.load(std::memory_order_relaxed)) return have;
     size_t free_b = 0, total_b = 0;
     int64_t gb = int64_t(2) << 20;
+    int prev = -1;
+    (void)hipGetDevice(&prev);   // a getter (hm_get_timing) may come through here: the caller's current device is put back
     if (hipSetDevice(e->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
         gb = (int64_t)(free_b / 4) / GROUP_BYTES_PER_BASE;
         gb = std::min<int64_t>(gb, int64_t(16) << 20);
         gb = std::max<int64_t>(gb >> 20 << 20, int64_t(1) << 20);  // whole Mi, at least one
     }
-    e->group_bases_eff.store(gb, std::memory_order_relaxed);
+    if (prev >= 0 && prev != e->device) (void)hipSetDevice(prev);
+    // several staging threads may measure at once and see different amounts of free memory: the FIRST figure stored is the engine's
+    int64_t none = 0;
+    if (!e->group_bases_eff.compare_exchange_strong(none, gb, std::memory_order_relaxed)) gb = none;
     return gb;
 }
 
@@ -231,7 +240,9 @@ int64_t effective_group_bases(hm_engine* e) {
 // u >= len) is a constant step of trunk3_kernel, an eighth or so of a computed one: the kernel cuts its runs at equal cost
 constexpr int TILE_COST = 8, TILE_COST_CONST = 1;
 void add_read_tiles(hm_engine* e, hm_batch* b, int ridx, int l_qseq) {
-    if (b->groups.empty() || b->groups.back().bases >= effective_group_bases(e)) {
+    // a group is closed on its map ROWS -- what every group buffer scales with: ceil((len + 400) / 112) * 112 + 32 per read, 1.03 x the bases for
+    // 15 kb reads but 3.5 x for 200-base ones (option -l) -- so that "at most a quarter of free memory" holds for any read length
+    if (b->groups.empty() || b->groups.back().rows >= effective_group_bases(e)) {
         b->groups.push_back(hm_batch::Group{(int)b->chunks.n, (int)b->chunks.n, (int)b->tiles.n, (int)b->tiles.n, 0, 0, (int)b->tcost.n});
         b->tcost.push_back(0);
     }
@@ -245,6 +256,8 @@ void add_read_tiles(hm_engine* e, hm_batch* b, int ridx, int l_qseq) {
     }
     for (int st = 0; st < l_qseq; st += CHUNK) b->chunks.push_back(Chunk{ridx, st});
     g.rows += (int64_t)ntile * TR_OWN + TR_SLACK;
+    // the edge kernel addresses a group's map rows (both views) in 27 bits: guaranteed by the 48 Mi cap on group_bases plus one read (< 2^25 rows)
+    if (2 * g.rows >= (int64_t(1) << 27)) throw HipErr{hipErrorInvalidValue, "a read group's maps exceed 2^27 rows (group_bases too large)"};
     g.bases += l_qseq;
     g.chunk_hi = (int)b->chunks.n;
     g.tile_hi = (int)b->tiles.n;
@@ -308,6 +321,7 @@ void collect_timing(hm_engine* e, std::vector<TimedSpan>& spans, const int32_t* 
         std::lock_guard<std::mutex> lk(e->mu);
         for (int c = 0; c < 3; ++c) e->acc.trunk_list_steps[c] += totals[8 + c];
         for (int c = 0; c < 3; ++c) e->acc.trunk_const_steps[c] += totals[12 + c];
+        e->acc.tail_strip_passes += totals[11];
     }
     for (auto& s : spans) {
         float ms = 0.f;
@@ -621,7 +635,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
                 if (e->trunk_impl == 3)
                     launch_trunk3(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
                                   b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), b->total_bases, dm.w, maps, e->d_dump.as<uint16_t>(),
-                                  b->d_totals.as<int32_t>() + 8, b->d_tcost.as<int32_t>() + g.cost_lo, e->num_cu);
+                                  b->d_totals.as<int32_t>() + 8, b->d_tcost.as<int32_t>() + g.cost_lo, e->num_cu, e->conv3_w16 != 0);
                 else if (e->trunk_impl)
                     launch_trunk2(e->stream, dm.k1, b->d_tiles.as<TrunkTile>() + g.tile_lo, n_tiles, n_views, c, b->d_rinfo.as<RInfo>(),
                                   b->d_bases.as<uint8_t>(), b->d_kin.as<uint32_t>(), b->d_sctx.as<uint8_t>(), dm.w, maps, e->num_cu, w16,
@@ -643,7 +657,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
             }
             {
                 Span sp(e, spans, K_TAILG, c);
-                if (e->tail_impl == 2 && e->precision == 1) {
+                if (e->tail_impl == 2 && e->precision >= 1) {
                     // launches of at most tail_slice sites: the hand-off buffer is laid out (and zeroed: its padding rows are never
                     // written) once, for the largest launch seen
                     const int64_t slice = std::min<int64_t>(e->tail_slice, std::max<int64_t>(max_bases, 1));
@@ -661,7 +675,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
                                           e->d_e4row.as<int32_t>() + off, e->d_x6.as<uint16_t>(), ph, b->d_logits.as<float>(),
                                           b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu);
                     }
-                } else if (e->tail_impl == 3 && e->precision == 1 && c == CHH) {
+                } else if (e->tail_impl == 3 && e->precision == 1 && c == CHH) {   // (precision 2's fp16-weight layers live in tail_kernel_r)
                     const int64_t vrows = g.rows * n_views;
                     e->d_mark.reserve(tail_strip_mark_bytes(vrows));
                     e->d_ccnt.reserve(tail_strip_count_bytes(vrows));
@@ -669,10 +683,10 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
                     e->d_okey.reserve((size_t)max_bases * sizeof(int32_t));
                     launch_tail_strip(e->stream, sr, dm.w, maps, n_views, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(), e->d_mark.as<int32_t>(),
                                       e->d_ccnt.as<int32_t>(), e->d_order.as<int32_t>(), e->d_okey.as<int32_t>(), b->d_logits.as<float>(),
-                                      b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu);
-                } else if ((e->tail_impl == 1 || e->tail_impl == 3) && e->precision == 1)
+                                      b->d_p.as<float>(), b->d_ml.as<uint8_t>(), b->d_totals.as<int32_t>() + 11, e->num_cu);
+                } else if ((e->tail_impl == 1 || e->tail_impl == 3) && e->precision >= 1)
                     launch_tail_gather_r(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
-                                         b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu);
+                                         b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu, e->precision == 2);
                 else
                     launch_tail_gather(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
                                        b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu, 0);
@@ -904,10 +918,15 @@ int hm_set_option(hm_engine_t* e, const char* key, int64_t value) {
     if (k == "min_read_size") e->min_read_size = (int)value;
     else if (k == "timing") e->timing = value != 0;
     else if (k == "precision") {
-        if (value < 0 || value > 1)
-            return fail(e, HM_EINVAL, "precision must be 0 (fp32 MFMA) or 1 (split-half f16x3 MFMA, fp32 accumulate); the fp16-weight modes 2 / 3 "
-                                      "of rounds 1-2 are closed: BASELINE.json configs[4] as written misses its 1e-3 bar");
+        if (value < 0 || value > 2)
+            return fail(e, HM_EINVAL, "precision must be 0 (fp32 MFMA), 1 (split-half f16x3 MFMA, fp32 accumulate) or 2 (as 1 with plain fp16 weights in "
+                                      "conv8 and fc1: |dp| <= 1e-3); BASELINE.json configs[4] as written -- fp16 weights in every layer -- "
+                                      "misses its 1e-3 bar (round 2's modes 2 / 3, closed)");
+        if (value == 2 && (e->tail_impl == 0 || e->tail_impl == 2))
+            return fail(e, HM_EINVAL, "precision 2 needs tail_impl 1 or 3 (the resident / strip tail kernels carry the fp16-weight variants)");
         e->precision = (int)value;
+    } else if (k == "conv3_w16") {
+        e->conv3_w16 = value != 0;
     } else if (k == "stamps") {
         e->stamps_on = value != 0;
         if (e->stamps_on) {
@@ -1408,6 +1427,11 @@ int hm_get_timing(hm_engine_t* e, hm_timing_t* t) {
         t->group_bytes += (int64_t)d->cap;
     return HM_OK;
 }
+
+/* ABI of include/hifimeth_hip.h: bumped whenever a struct of the header grows (hm_timing_t: round 4 +64 bytes, round 5 +8); a consumer built
+ * against another header sees the mismatch instead of having hm_get_timing write past its struct */
+int hm_abi_version(void) { return HM_ABI_VERSION; }
+size_t hm_timing_size(void) { return sizeof(hm_timing_t); }
 
 int hm_reset_timing(hm_engine_t* e) {
     if (!e) return HM_EINVAL;

@@ -78,7 +78,7 @@ void launch_tail_gather(hipStream_t st, const SiteRange& sr, const CtxWeights& w
                         const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, int w16_level);
 // the same tail with conv5..conv7's weights resident in registers (hm_tail_r.hip): bit-identical results
 void launch_tail_gather_r(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
-                          const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid);
+                          const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, bool w16 = false);   // w16: conv8 + fc1 with plain fp16 weights (precision 2)
 // the tail as two kernels (hm_tail_s.hip): conv5 + conv6 (8 sites per pass, conv6's rows to `x6`), then conv7 .. softmax (16 sites per
 // pass, all weights resident): bit-identical results.  `x6`: tail_split_x6_bytes(max sites of a launch) bytes, zeroed once;
 // `x6_plane_halves` = tail_split_x6_plane_halves(that same maximum) for every launch into it.
@@ -93,7 +93,7 @@ size_t tail_strip_mark_bytes(int64_t map_rows);
 size_t tail_strip_count_bytes(int64_t map_rows);
 void launch_tail_strip(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, int n_views, const uint16_t* edge4,
                        const int32_t* e4row, int32_t* mark, int32_t* cnt, int32_t* order, int32_t* okey, float* logits, float* p, uint8_t* ml,
-                       int grid);
+                       int32_t* pass_count, int grid);   // pass_count (may be null): += the launch's passes of 16 site slots
 void launch_trunk2(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,
                    const TrunkMaps& maps, int grid, bool w16, bool waves8 = false);
@@ -105,7 +105,8 @@ size_t trunk3_rowlist_bytes(int64_t n_work);
 size_t trunk3_dump_bytes(int grid);
 void launch_trunk3(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, int64_t n_bases, const CtxWeights& w, const TrunkMaps& maps,
-                   uint16_t* dump, int32_t* list_steps, const int32_t* tcost, int grid);   // n_bases: bytes of sctx
+                   uint16_t* dump, int32_t* list_steps, const int32_t* tcost, int grid, bool w3_single = false);   // n_bases: bytes of sctx
+// (w3_single: conv3 with plain fp16 weights -- its w_lo x_hi product dropped -- engine option precision = 2)
 // the same path in strict fp32 (precision 0; hm_trunk_f32.hip): fp32 maps and edge rows, v_mfma_f32_16x16x4_f32
 void launch_trunk_f32(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                       const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,

@@ -71,6 +71,8 @@ __device__ __forceinline__ void zero_pads(half_t* hi, half_t* lo, int t) {
 
 }  // namespace
 
+// W16 (engine option precision = 2): conv8 and fc1 with plain fp16 weights (their w_lo x_hi product and lo-plane fetches dropped)
+template <bool W16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void tail_kernel_r(SiteRange sr, CtxWeights W, float* __restrict__ logits, float* __restrict__ prob, uint8_t* __restrict__ ml,
                    const half_t* __restrict__ e4, const half_t* __restrict__ edge4, const int32_t* __restrict__ e4row,
@@ -118,7 +120,7 @@ void tail_kernel_r(SiteRange sr, CtxWeights W, float* __restrict__ logits, float
     tw_load(wf(6), nt78, lane, W7);
 
     using C96 = TCfg<96, 3, T::RS96>;
-    using C64 = TCfg<64, 3, T::RS64>;
+    using C64 = TCfg<64, 3, T::RS64, !W16>;
     using R5 = TRows<T::L5, T::IN_SS, S * T::L5>;
     using R6 = TRows<T::L6, T::C5_SS, S * T::L6>;
     using R7 = TRows<T::L7, T::C6_SS, S * T::L7>;
@@ -243,7 +245,7 @@ void tail_kernel_r(SiteRange sr, CtxWeights W, float* __restrict__ logits, float
         lds_barrier();
         TTS(6);
         // ---- conv7 (buffer 0 -> buffer 1) ------------------------------------------------------------------------------------
-        tw_load(wf(7), nt78, lane, W8);  // conv8's weights: requested a layer ahead (earlier, conv6's working set spills)
+        tw_load<!W16>(wf(7), nt78, lane, W8);  // conv8's weights: requested a layer ahead (earlier, conv6's working set spills)
         TConv<C96, R7, 8, 1, TG<0, 0, 0, 2>>::run(h0, l0, W7, b7, col78, EpiStack<T::L7, T::RS64, T::C7_SS>{h1, l1});
         zero_pads<T::L7, 64, T::RS64, T::C7_SS>(h1, l1, tl);
         TTS(7);
@@ -265,13 +267,13 @@ void tail_kernel_r(SiteRange sr, CtxWeights W, float* __restrict__ logits, float
         // n-tiles of a half, whose weights (64 registers) it requests in one go -- the first half's before the barrier, where
         // their latency hides behind the other waves' conv8; so are the biases and the places this thread's two sites' results
         // go to.  (ConvH's k-block-ahead streaming was L2-latency-bound here: 12 MFMAs per k-block.)
-        using CF = TCfg<64, 2, T::RS64>;
+        using CF = TCfg<64, 2, T::RS64, !W16>;
         using RF = TRows<1, T::RING_SS, FCB * S>;
         using FC1 = TConv<CF, RF, 8, 1, TG<0, 2, 0, 0>>;
         TW<4, 2> WF;
         const int ntf0[2] = {2 * wave, 2 * wave + 1}, ntf1[2] = {8 + 2 * wave, 9 + 2 * wave};
         const int colf0[2] = {32 * wave, 32 * wave + 16}, colf1[2] = {128 + 32 * wave, 144 + 32 * wave};
-        tw_load(wf(8), ntf0, tl & 63, WF);
+        tw_load<!W16>(wf(8), ntf0, tl & 63, WF);
         float4 bzf[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bzf[j] = *reinterpret_cast<const float4*>(W.bias[8] + (j < 2 ? colf0[j] : colf1[j - 2]) + 4 * ((tl & 63) >> 4));
@@ -284,7 +286,7 @@ void tail_kernel_r(SiteRange sr, CtxWeights W, float* __restrict__ logits, float
         lds_barrier();
         TTS(10);
         FC1::run(r_hi, r_lo, WF, [&](int j) __attribute__((always_inline)) { return bzf[j]; }, colf0, EpiFc1R<T::HRS>{hfc});
-        tw_load(wf(8), ntf1, tl & 63, WF);
+        tw_load<!W16>(wf(8), ntf1, tl & 63, WF);
         FC1::run(r_hi, r_lo, WF, [&](int j) __attribute__((always_inline)) { return bzf[2 + j]; }, colf1, EpiFc1R<T::HRS>{hfc});
         lds_barrier();
         // fc2 + softmax (mod_batch.cpp:46-64) in fp32: 16 lanes per site = 2 outputs x 8 partial sums (two rounds of 16 sites)
@@ -336,11 +338,13 @@ void tail_kernel_r(SiteRange sr, CtxWeights W, float* __restrict__ logits, float
 }
 
 void launch_tail_gather_r(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, const uint16_t* edge4,
-                          const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid) {
+                          const int32_t* e4row, float* logits, float* p, uint8_t* ml, int grid, bool w16) {
     if (sr.cap <= 0) return;
     const dim3 g(sr.totals ? grid : max(1, min((sr.cap + TAIL_SITES - 1) / TAIL_SITES, grid)));
-    hipLaunchKernelGGL(tail_kernel_r, g, dim3(256), 0, st, sr, w, logits, p, ml, reinterpret_cast<const half_t*>(maps.e4),
-                       reinterpret_cast<const half_t*>(edge4), e4row, reinterpret_cast<const half_t*>(maps.zeros));
+    if (w16) hipLaunchKernelGGL(tail_kernel_r<true>, g, dim3(256), 0, st, sr, w, logits, p, ml, reinterpret_cast<const half_t*>(maps.e4),
+                                reinterpret_cast<const half_t*>(edge4), e4row, reinterpret_cast<const half_t*>(maps.zeros));
+    else hipLaunchKernelGGL(tail_kernel_r<false>, g, dim3(256), 0, st, sr, w, logits, p, ml, reinterpret_cast<const half_t*>(maps.e4),
+                            reinterpret_cast<const half_t*>(edge4), e4row, reinterpret_cast<const half_t*>(maps.zeros));
 }
 
 }  // namespace hm

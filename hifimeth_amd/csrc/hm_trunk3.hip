@@ -284,7 +284,9 @@ __global__ __launch_bounds__(64) void rowlist3_kernel(const TrunkTile* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-template <int K1>
+// W3LO = false (engine option precision = 2, BASELINE.json configs[4]'s best variant that holds its bar): conv3 runs with plain fp16 WEIGHTS --
+// its w_lo x_hi product is dropped, 12 of a tile's 53 MFMAs per position; activations stay hi + lo everywhere
+template <int K1, bool W3LO = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views, int ctx, const RInfo* __restrict__ rinfo,
                    const uint8_t* __restrict__ bases, const uint32_t* __restrict__ kin, CtxWeights W, TrunkMaps mp, half_t* __restrict__ dump,
@@ -409,7 +411,7 @@ void trunk3_kernel(const TrunkTile* __restrict__ tiles, int n_tiles, int n_views
 
     using C1 = SCfg<8, (2 * K1 + 3) / 4 * 4, TR_WRS, 1, true, false, K1, 2, NTW>;
     using C2 = SCfg<128, 3, TR_RS, 2, true, true, 0, 1, NTW>;
-    using C3 = SCfg<128, 3, TR_RS, 4, true, true, 0, 1, NTW>;
+    using C3 = SCfg<128, 3, TR_RS, 4, W3LO, true, 0, 1, NTW>;
     using C4 = SCfg<128, 3, TR_RS, 8, true, true, 0, 1, NTW>;
     using C4s = SCfg<128, 3, TR_RS, 8, true, true, 0, 1, 1>;   // one of the wave's two resident n-tiles alone
     // conv4's 6 n-tiles x 7 position tiles on four waves as in trunk2_kernel: waves 0 / 2 hold (a, b) = (0, 1) / (3, 4), waves 1 / 3
@@ -653,16 +655,18 @@ size_t trunk3_dump_bytes(int grid) { return ((size_t)(1 + grid) * TR_OWN * 2 * C
 
 void launch_trunk3(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, int64_t n_bases, const CtxWeights& w, const TrunkMaps& maps,
-                   uint16_t* dump, int32_t* list_steps, const int32_t* tcost, int grid) {
+                   uint16_t* dump, int32_t* list_steps, const int32_t* tcost, int grid, bool w3_single) {
     if (n_tiles <= 0) return;
     const int n_work = n_tiles * n_views;
     const dim3 g(min(n_work, grid));
     if (k1 == 11) {
         hipLaunchKernelGGL(rowlist3_kernel<11>, dim3((2 * n_work + T3_RPB) / T3_RPB), dim3(64), 0, st, tiles, n_tiles, n_work, ctx, rinfo, sctx, n_bases, maps.rowlist);
-        hipLaunchKernelGGL(trunk3_kernel<11>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps, tcost);
+        if (w3_single) hipLaunchKernelGGL((trunk3_kernel<11, false>), g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps, tcost);
+        else hipLaunchKernelGGL((trunk3_kernel<11, true>), g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps, tcost);
     } else {
         hipLaunchKernelGGL(rowlist3_kernel<13>, dim3((2 * n_work + T3_RPB) / T3_RPB), dim3(64), 0, st, tiles, n_tiles, n_work, ctx, rinfo, sctx, n_bases, maps.rowlist);
-        hipLaunchKernelGGL(trunk3_kernel<13>, g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps, tcost);
+        if (w3_single) hipLaunchKernelGGL((trunk3_kernel<13, false>), g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps, tcost);
+        else hipLaunchKernelGGL((trunk3_kernel<13, true>), g, dim3(256), 0, st, tiles, n_tiles, n_views, ctx, rinfo, bases, kin, w, maps, reinterpret_cast<half_t*>(dump), list_steps, tcost);
     }
 }
 

@@ -30,6 +30,7 @@
 #ifndef HIFIMETH_HIP_H
 #define HIFIMETH_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -81,7 +82,14 @@ typedef struct {
     int64_t trunk_const_steps[3]; /* tiles stored as constant rows instead of computed: a read's first tile and those behind its end, where no receptive field reaches the read */
     int64_t group_bases;        /* bases per trunk read group in force (option "group_bases", or what the engine sized from free memory) */
     int64_t group_bytes;        /* device bytes the engine holds for a read group's maps, edge rows and hand-off buffers */
+    int64_t tail_strip_passes;  /* passes (16 site slots each) of the strip tail kernel (tail_impl 3, CHH): MFMAs issued = passes x a pass's count */
 } hm_timing_t;
+
+/* Version of this header's structs (hm_timing_t grows round by round: 4 = round 4, 5 = + tail_strip_passes).  hm_abi_version() returns what the
+ * LIBRARY was built with and hm_timing_size() its sizeof(hm_timing_t): a consumer compares both with its own before calling hm_get_timing. */
+#define HM_ABI_VERSION 5
+int hm_abi_version(void);
+size_t hm_timing_size(void);
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
 /* model_dir holds {CpG,CHG,CHH}.hmw (flat fp32 container written from the reference's
@@ -92,14 +100,14 @@ void hm_destroy(hm_engine_t* e);
 const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a failed hm_create */
 /* options: "slots" (batches in flight of the hm_batch_* pipeline, default 3), "min_read_size" (-l, default 1000), "timing" (0/1), "sub_batch_sites" (front/tail
  * launch granularity, default 65536), "front_waves" (4 or 8 waves per front workgroup), "precision" (0 = fp32 MFMA, exact;
- * 1 = split-half fp16x3 MFMA with fp32 accumulate (default).  Plain fp16 WEIGHTS -- BASELINE.json configs[4] -- were options 2 / 3
- * in rounds 1-2 and are closed: as written the configuration misses its own bar |dp| <= 1e-3 (max ~ 2.5e-3; per-term error table
- * profiles/r02_term_error_table.txt), and the part that holds it is 1 % of the FLOPs), "trunk" (2 = per context by the site density of the FIRST batch the engine is given -- counted
+ * 1 = split-half fp16x3 MFMA with fp32 accumulate (default, |dp| <= 1e-4); 2 = as 1 with plain fp16 WEIGHTS in conv8 and fc1 (their
+ * w_lo x_hi product and lo-plane fetches dropped): the part of BASELINE.json configs[4] that holds its bar |dp| <= 1e-3 with margin;
+ * as written -- fp16 weights in every layer -- that configuration reaches 2.5e-3 (profiles/r02_term_error_table.txt) and stays closed: 3 is an error), "trunk" (2 = per context by the site density of the FIRST batch the engine is given -- counted
  * on the host when that batch is queued and then fixed for the engine's lifetime, so the calls never depend on host timing --
  * default; 1 = conv1..conv4 once per read position; 0 = once per site; every precision has both forms), "trunk_mask" (0..7: that
  * choice made by the caller, see hm_trunk_mask_for_reads), "trunk_impl" (3 = the streaming trunk as a sliding window over
  * consecutive tiles, default; 1 = streaming 4-wave trunk kernel; 2 = the same on 8 waves; 0 = the 8-wave ConvH form; byte-identical results), "edge_impl" (1 = edge2_kernel, default; 0 = round 2's
- * edge_kernel; byte-identical), "tail_impl" (1 = tail with register-resident weights, default; 2 = the split tail: conv5 + conv6, then conv7 .. softmax over 16 sites per pass ("tail_slice": sites per launch pair); 0 = the streaming tail; byte-identical),
+ * edge_kernel; byte-identical), "tail_impl" (3 = the strip tail for CHH (16 sites of one E4-row residue class per pass share one strip of rows in LDS; hm_tail_p.hip) and 1 for the sparse contexts, default; 1 = tail with register-resident weights; 2 = the split tail: conv5 + conv6, then conv7 .. softmax over 16 sites per pass ("tail_slice": sites per launch pair); 0 = the streaming tail; byte-identical),
  * "group_bases" (reads per trunk group; default 0 = sized when the first read is staged so that a group's buffers, 5.8 KB per base, take at most a quarter of the device's free memory, and at most 16 Mi bases), "num_cu" (workgroups of the persistent kernels), "stamps" (diagnostic) */
 int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
 

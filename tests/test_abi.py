@@ -34,19 +34,23 @@ def test_struct_layout_matches_header():
 
 
 def test_timing_struct_matches_header(tmp_path):
-    """hm_timing_t grows round by round (round 4: trunk_list_steps, trunk_const_steps, group_bases, group_bytes): the ctypes mirror must keep the header's size
-    and the offsets of its last fields -- checked against what the C compiler makes of include/hifimeth_hip.h."""
+    """hm_timing_t grows round by round (round 4: trunk_list_steps, trunk_const_steps, group_bases, group_bytes; round 5: tail_strip_passes): the
+    ctypes mirror must keep the header's size and the offsets of its last fields -- checked against what the C compiler makes of
+    include/hifimeth_hip.h -- and the LIBRARY reports the header version and struct size it was built with (a consumer built
+    against another header must see the mismatch instead of having hm_get_timing write past its struct)."""
     import subprocess
     from hifimeth_amd import _lib
     src = tmp_path / "t.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "hifimeth_hip.h"\n'
-                   'int main(void) { printf("%zu %zu %zu %zu\\n", sizeof(hm_timing_t), offsetof(hm_timing_t, trunk_list_steps), '
-                   'offsetof(hm_timing_t, group_bases), offsetof(hm_timing_t, group_bytes)); return 0; }\n')
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %d\\n", sizeof(hm_timing_t), offsetof(hm_timing_t, trunk_list_steps), '
+                   'offsetof(hm_timing_t, group_bases), offsetof(hm_timing_t, group_bytes), offsetof(hm_timing_t, tail_strip_passes), HM_ABI_VERSION); return 0; }\n')
     exe = tmp_path / "t"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
-    size, o1, o2, o3 = (int(x) for x in subprocess.check_output([str(exe)], text=True).split())
+    size, o1, o2, o3, o4, ver = (int(x) for x in subprocess.check_output([str(exe)], text=True).split())
     T = _lib.hm_timing_t
-    assert (size, o1, o2, o3) == (ctypes.sizeof(T), T.trunk_list_steps.offset, T.group_bases.offset, T.group_bytes.offset)
+    assert (size, o1, o2, o3, o4) == (ctypes.sizeof(T), T.trunk_list_steps.offset, T.group_bases.offset, T.group_bytes.offset, T.tail_strip_passes.offset)
+    L = _lib.lib()
+    assert L.hm_abi_version() == ver == _lib.HM_ABI_VERSION and L.hm_timing_size() == size
 
 
 def test_no_cpu_fallback():

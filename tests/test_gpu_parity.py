@@ -266,17 +266,43 @@ def test_split_half_precision_mode(mc, oracle, oracle_models):
         mc.set_option("precision", mc.precision)
 
 
-def test_fp16_weight_modes_are_closed(mc):
-    """BASELINE.json configs[4] (plain fp16 CNN weights, |dp| <= 1e-3) is CLOSED as failed: measured in rounds 1-2, the
-    configuration as written reaches 2.5e-3 on 0.2 % of sites, and the variant inside the bar (fp16 weights in conv6..conv8
-    only: 8.8e-4 over 1 M sites, no margin at configs[2]'s 1.1 G sites) is 1 % of the FLOPs and bought nothing
-    (profiles/r02_term_error_table.txt, profiles/r02_bench_precision2.json, README).  The engine no longer offers the modes:
-    asking for them is an error, not a silent fallback."""
-    from hifimeth_amd import HifimethError
-    for mode in (2, 3):
+def test_fp16_weight_mode_holds_its_bar_and_the_literal_config_stays_closed(oracle, oracle_models):
+    """BASELINE.json configs[4] (plain fp16 CNN weights, |dp| <= 1e-3).  AS WRITTEN -- fp16 weights in every layer -- it was measured in
+    rounds 1-2 at 2.5e-3 and stays closed (`precision` 3 is an error, not a silent fallback).  What holds the bar with margin is offered
+    as `precision` = 2: plain fp16 weights (the w_lo x_hi product and the lo plane's fetches dropped) in conv8 and fc1, in both tail kernels;
+    activations stay hi + lo (profiles/r05_parity_sweep_precision2.txt: the multi-million-site sweep; conv3 alone -- the layer VERDICT r04
+    proposed -- reaches 1.3e-3 there: profiles/r05_parity_sweep_conv3_w16.txt).  Here: the mode is accepted, it is
+    a different arithmetic from mode 1 (some p differ), and its calls hold 1e-3 against the fp32 oracle on configs[2]-like reads (GC 0.36)
+    and on human-like ones (GC 0.41, CpG depleted), site lists and order unchanged."""
+    from hifimeth_amd import HifimethError, MethylationCaller
+    from hifimeth_amd.synth import synth_slab
+    with MethylationCaller(device=0) as m:
         with pytest.raises(HifimethError):
-            mc.set_option("precision", mode)
-    mc.set_option("precision", mc.precision)
+            m.set_option("precision", 3)
+    for gc, oe in ((0.36, 1.0), (0.41, 0.24)):
+        reads = synth_slab(8, seed=411, gc=gc, cpg_oe=oe, median_len=7000, sigma=0.4, frac_wide=0.2)
+        with MethylationCaller(device=0) as m:
+            m.set_option("trunk", 1)
+            ref = m.call(reads).copy()
+        with MethylationCaller(device=0) as m:
+            m.set_option("trunk", 1)
+            m.set_option("precision", 2)
+            got = m.call(reads).copy()
+        assert len(got) == len(ref) > 5000
+        for f in ("read_id", "qoff", "strand", "ctx"):
+            assert np.array_equal(got[f], ref[f])
+        assert (got["p"] != ref["p"]).mean() > 0.5 and float(np.abs(got["p"] - ref["p"]).max()) < 1e-3
+        worst = 0.0
+        for rid, rd in enumerate(reads):
+            if not rd.has_kinetics() or rd.l_qseq < 1000:
+                continue
+            want = oracle.call_read(oracle_models, 7, rd)
+            g = got[got["read_id"] == rid]
+            order = np.lexsort((want["qoff"], want["strand"]))
+            assert len(g) == len(order) and np.array_equal(g["qoff"], want["qoff"][order])
+            worst = max(worst, float(np.abs(g["p"] - want["p"][order]).max()))
+            assert int(np.abs(g["scaled_prob"].astype(int) - want["ml"][order].astype(int)).max()) <= 1
+        assert worst <= 1e-3, worst   # the tolerance BASELINE.json configs[4] states
 
 
 def test_group_size_option_is_bounded():
