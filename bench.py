@@ -149,19 +149,19 @@ def parity_sample(reads, per_group=32):
 def quoted_traffic(tm, launches, sites):
     """HBM traffic of the trunk kernel.  HBM bytes come from PMC counters, which need rocprofv3 passes of their own (one counter
     group per run) and cannot be read from inside this process: `traffic` (measured in THIS run) is therefore null, and the figure
-    of the round's kept full-size pass (profiles/r04_traffic.json, written by tools/pmc_derive.py from tools/prof_r04.sh traffic:
+    of the round's kept full-size pass (profiles/r05_traffic.json, written by tools/pmc_derive.py from tools/prof_r05.sh traffic:
     this same command, gfx950 corrections applied) is given under `traffic_quoted`, with its source."""
     alg = 28.0 * sites / max(1, launches)   # SURVEY.md 8(d): ~16 B of raw input + 12 B of result per site
     out = {"traffic": None, "algorithmic_bytes": alg,
-           "traffic_note": "HBM bytes need separate rocprofv3 --pmc passes (tools/prof_r04.sh traffic); see traffic_quoted"}
-    path = os.path.join(ROOT, "profiles", "r04_traffic.json")
+           "traffic_note": "HBM bytes need separate rocprofv3 --pmc passes (tools/prof_r05.sh traffic); see traffic_quoted"}
+    path = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_traffic.json", "r04_traffic.json")) if os.path.exists(q)), "")
     try:
         q = json.load(open(path))
         k = q["trunk_kernel"]
         per_pos = {0: k["k11"], 1: k["k11"], 2: k["k13"]}
         tot = sum(tm["trunk_positions"][c] * (per_pos[c]["read_B_per_position"] + per_pos[c]["write_B_per_position"]) for c in range(3))
         out["traffic_quoted"] = {"bytes_per_launch": tot / max(1, launches), "over_algorithmic": tot / max(1, launches) / alg,
-                                 "source": "profiles/r04_traffic.json", "kernel": q.get("kernel"), "command": q.get("command"),
+                                 "source": "profiles/" + os.path.basename(path), "kernel": q.get("kernel"), "command": q.get("command"),
                                  "commit": q.get("commit"),
                                  "note": "HBM-side bytes per view position measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the "
                                          "full-size bench command (gfx950: FETCH_SIZE doubled), times this run's positions per launch; the "

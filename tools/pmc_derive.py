@@ -1,4 +1,4 @@
-"""Derived per-kernel figures from a rocprofv3 --pmc summary written by tools/prof_r04.sh (pmc_summary.txt):
+"""Derived per-kernel figures from a rocprofv3 --pmc summary written by tools/prof_r05.sh (prof_r04.sh) (pmc_summary.txt):
    python tools/pmc_derive.py gpurun_out/prof_r04/pmc_summary.txt [bench.json of a PMC pass] [traffic.json to write] [commit] > profiles/r04_pmc_derived.txt
 With the optional arguments the HBM-side bytes of the trunk kernel are also written per VIEW POSITION (bytes per launch / the
 positions a launch of that context covered in the profiled run): what bench.py gives as roofline.traffic_quoted.
@@ -23,7 +23,7 @@ for k, c in sorted(d.items()):
     gui, mf = g("GRBM_GUI_ACTIVE"), g("SQ_INSTS_MFMA")
     wc = max(g("SQ_WAVE_CYCLES"), 1.0)
     k = k.replace("void hm::", "")
-    k = "tail_kernel_r (resident weights)" if k == "tail_kernel_r" else k
+    k = "tail_kernel_r (resident weights)" if k == "tail_kernel_r" else "tail_kernel_p (strip tail, CHH)" if k == "tail_kernel_p" else k
     print(f"{k:36s} launches {c['GRBM_GUI_ACTIVE'][1]:4d}  mean launch {gui / 8 / 2.1e6:7.3f} ms(@2.1GHz)  "
           f"MFMA busy {g('SQ_VALU_MFMA_BUSY_CYCLES') / (gui / 8 * 1024):.3f}  MFMA/launch {mf:.3g}  VALU/MFMA {g('SQ_INSTS_VALU') / mf:.2f}  "
           f"LDS/MFMA {g('SQ_INSTS_LDS') / mf:.2f}  VMEM_RD/MFMA {g('SQ_INSTS_VMEM_RD') / mf:.2f}  "
@@ -39,8 +39,9 @@ if len(sys.argv) > 3:
     kern = next((t for t in TR if any(t in k for k in d)), TR[0])
     out = {"_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over `python bench.py --steps 2 --warmup 1 "
                       "--no-extras --no-cpu-baseline` (the driver's full-size slabs and default options); FETCH_SIZE doubled (gfx950 tallies 128-B "
-                      "requests as 64 B: MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported (calibrated for 16-B-per-lane stores; the trunk's E4 rows "
-                      "leave as 8-B-per-lane stores: uncalibrated width); Infinity-Cache hits are counted, not excluded",
+                      "requests as 64 B: MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported: exact for the trunk's 8-B-per-lane row stores as well "
+                      "(profiles/r05_write_size_calibration.txt: counter / bytes = 1.0000 for 16-B and 8-B stores, contiguous and in the trunk's "
+                      "pattern); Infinity-Cache hits are counted, not excluded",
            "kernel": kern, "command": "python bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline", "commit": sys.argv[4] if len(sys.argv) > 4 else None,
            "trunk_kernel": {}}
     for key, tag, cs in (("k11", "", (0, 1)), ("k13", "<13", (2,))):
