@@ -174,7 +174,8 @@ struct hm_engine {
     // 3 (default) = the strip tail (hm_tail_p.hip) for CHH -- 16 sites of one residue class per pass sharing a strip of E4 rows in LDS --
     // and tail_kernel_r for the sparse contexts (their sites are too far apart to share rows)
     int tail_impl = 3;
-    int64_t tail_slice = int64_t(1) << 21;  // sites per launch pair of the split tail: its hand-off buffer holds 7.5 KB per site
+    int64_t tail_slice = int64_t(1) << 21;  // sites per launch pair of the split tail (option, not the default): its hand-off buffer holds 3.7 KB per site (2 planes x 9 rows x 208 B:
+                                            // 7.9 GB at this slice, allocated on first use and NOT part of GROUP_BYTES_PER_BASE's quarter-of-free-memory budget)
     // trunk = 2 is decided ONCE per engine, from the reads of the first non-empty batch that is queued (counted on the
     // host, estimate_density): the choice must not depend on which batches happen to have finished when the next one is
     // queued -- the two paths differ by fp32 re-association (~1e-5 in p), and the reference's output is deterministic.

@@ -51,9 +51,10 @@ def _worker(rank, world, port, q):
     mine = D.slab_assignment(len(slabs), rank, world)
     calls = [_oracle_calls(reads, slabs[s], models) for s in mine]
     sites, secs = D.job_throughput(dist, sum(len(c) for c in calls), 1.0 + rank)
+    rows = D.gather_rank_stats(dist, [sum(len(c) for c in calls), 1.0 + rank, rank])   # what bench.py's `ranks` block is made of
     allc = D.gather_calls(dist, calls, mine, len(slabs), CALL_DTYPE)
     if rank == 0:
-        q.put((sites, secs, allc.tobytes()))
+        q.put((sites, secs, allc.tobytes(), rows))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,10 +72,13 @@ def test_two_rank_sharding_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    sites, secs, raw = q.get(timeout=240)
+    sites, secs, raw, rows = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    # every rank's own (sites, seconds, rank) on rank 0, in rank order: the bench line's per-rank figures
+    assert len(rows) == 2 and [r[2] for r in rows] == [0.0, 1.0] and [r[1] for r in rows] == [1.0, 2.0] and sum(r[0] for r in rows) == sites
+    assert D.gather_rank_stats(None, [3, 0.5]) == [[3.0, 0.5]]
     reads = synth_reads(7, seed=4, median_len=1300, sigma=0.2, frac_short=0.2, frac_missing=0.1)
     models = [O.Model(os.path.join(WEIGHTS, "CpG.hmw")), None, None]
     single = _oracle_calls(reads, range(len(reads)), models)
@@ -85,6 +89,27 @@ def test_two_rank_sharding_matches_single_process():
     assert (s1, t1) == (5.0, 0.5)
     g = D.gather_calls(None, [single[:3], single[3:]], [0, 1], 2, CALL_DTYPE)
     assert g.tobytes() == single.tobytes()
+
+
+def test_gpu_count_without_opening_the_device(monkeypatch, tmp_path):
+    """dist.gpu_count_no_init: KFD topology nodes with SIMDs, cut down by *_VISIBLE_DEVICES; -1 where there is no KFD sysfs (this container).
+    A launcher (bench.py --gpus N) or a barrier-only rank (call_dist) must not become one more process that holds the GPU."""
+    import glob as _glob
+    from hifimeth_amd import dist as D
+    nodes = []
+    for i, simd in enumerate((0, 256, 256, 0, 256)):     # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+        nodes.append(str(d / "properties"))
+    monkeypatch.setattr(_glob, "glob", lambda pat: nodes if "kfd" in pat else [])
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert D.gpu_count_no_init() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert D.gpu_count_no_init() == 2
+    monkeypatch.setattr(_glob, "glob", lambda pat: [])
+    assert D.gpu_count_no_init() == -1
 
 
 def _payload(path):

@@ -35,6 +35,15 @@ def _check_common(d, n_gpus):
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1 and "traffic" in rf
+    # every MFMA kernel's executed rate, and the device's over the wall time (VERDICT r04 #6a)
+    bk = rf["by_kernel"]
+    assert abs(sum(bk[k]["share_of_device_ms"] for k in ("trunk", "edge", "tail")) - 1) < 1e-9
+    for k in ("trunk", "edge", "tail"):
+        assert 0 < bk[k]["frac"] < 1 and abs(bk[k]["frac"] - bk[k]["executed"] / rf["peak"]) < 1e-12
+    assert abs(bk["trunk"]["frac"] - rf["frac"]) < 1e-12 and 0 < bk["whole_device"]["frac_over_timed_region"] < bk["trunk"]["frac"]
+    assert bk["tail"]["strip_tail_passes"] > 0 and 1 <= bk["tail"]["strip_tail_sites_per_pass"] <= 16
+    rk = d["ranks"]
+    assert rk["world"] == n_gpus and len(rk["sites_per_s"]) == n_gpus and abs(sum(rk["sites_per_s"]) - d["value"]) < 0.1 * d["value"]
 
 
 def test_bench_line_single_gpu_with_cpu_baseline():
