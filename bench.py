@@ -646,6 +646,10 @@ def main():
                                    "hm_batch_submit_read -> async H2D -> scan + windows + CNN -> packed D2H, double-buffered; "
                                    "staging and both copies inside the timed region",
                        "group_bases": GROUP_BASES, "group_bytes": int(tm["group_bytes"]),
+                       "group_size_note": "group_bases = map rows per trunk read group, default a quarter of the device's FREE memory (12 Mi on an empty "
+                                          "288 GB part: group_bytes of HBM held, per rank and per GPU -- not host memory); same-box A/B 2 Mi against the "
+                                          "default: 60.65 / 61.10 against 61.60 / 61.53 M sites/s = +1.0 % (profiles/r05_ab_group.txt); option group_bases "
+                                          "sets it by hand",
                        "kernel_path_by_context": {n: ("dense trunk" if tm["trunk_ms"][c] > 0 else "per site") for c, n in enumerate(("CpG", "CHG", "CHH"))},
                        "reads_per_step": args.reads, "distinct_slabs": n_pool, "staging_threads": mc.stage_threads,
                        "bases_per_gpu": int(bases_job), "sites_per_gpu": int(sites_job),
