@@ -31,6 +31,9 @@ __device__ __forceinline__ uint32_t split_lo2(uint32_t h01, float x0, float x1) 
         "v_fma_mixhi_f16 %0, -%1, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
         : "=&v"(l)
         : "v"(h01), "v"(x0), "v"(x1));
+#ifdef HM_XP_LO_BITS   // experiment: the lo halves rounded to 10 - HM_XP_LO_BITS mantissa bits (operand toggling vs the clock the chip holds)
+    l = (l + ((1u << (HM_XP_LO_BITS - 1)) * 0x00010001u)) & ((0xffffu << HM_XP_LO_BITS & 0xffffu) * 0x00010001u);
+#endif
     return l;
 }
 

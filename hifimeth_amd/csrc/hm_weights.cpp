@@ -488,6 +488,10 @@ PackedModel pack_model(const HostModel& m) {
         uint16_t hb, lb;
         memcpy(&hb, &h, 2);
         memcpy(&lb, &l, 2);
+        if (const char* mb = getenv("HM_XP_WLO_MASK_BITS")) {   // experiment (see hm_convh.h HM_XP_LO_BITS): round to nearest at 10 - n mantissa bits
+            const int n = atoi(mb);
+            if (n > 0) lb = (uint16_t)((lb + (1u << (n - 1))) & (0xffffu << n));
+        }
         return (uint32_t)hb | ((uint32_t)lb << 16);
     };
     for (int i = 0; i < 9; ++i) {  // conv1..conv8, fc1: [n-tile][k-block of 32][plane][lane][8 halves]
