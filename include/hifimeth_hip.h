@@ -108,7 +108,8 @@ const char* hm_last_error(const hm_engine_t* e); /* e may be NULL: error of a fa
  * choice made by the caller, see hm_trunk_mask_for_reads), "trunk_impl" (3 = the streaming trunk as a sliding window over
  * consecutive tiles, default; 1 = streaming 4-wave trunk kernel; 2 = the same on 8 waves; 0 = the 8-wave ConvH form; byte-identical results), "edge_impl" (1 = edge2_kernel, default; 0 = round 2's
  * edge_kernel; byte-identical), "tail_impl" (3 = the strip tail for CHH (16 sites of one E4-row residue class per pass share one strip of rows in LDS; hm_tail_p.hip) and 1 for the sparse contexts, default; 1 = tail with register-resident weights; 2 = the split tail: conv5 + conv6, then conv7 .. softmax over 16 sites per pass ("tail_slice": sites per launch pair); 0 = the streaming tail; byte-identical),
- * "group_bases" (reads per trunk group; default 0 = sized when the first read is staged so that a group's buffers, 5.8 KB per base, take at most a quarter of the device's free memory, and at most 16 Mi bases), "num_cu" (workgroups of the persistent kernels), "stamps" (diagnostic) */
+ * "group_bases" (reads per trunk group; default 0 = sized when the first read is staged so that a group's buffers, 5.8 KB per base, take at most a quarter of the device's free memory, and at most 16 Mi bases), "num_cu" (workgroups of the persistent kernels), "conv3_w16" (diagnostic: conv3 of the dense trunk with plain fp16 weights -- measured ABOVE the 1e-3 bar,
+ * part of no mode), "stamps" (diagnostic) */
 int hm_set_option(hm_engine_t* e, const char* key, int64_t value);
 
 /* ---- staging: the EvalKmerFeaturesGenerator::init seam ----------------------------------- */
