@@ -596,6 +596,12 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
     e->d_dump.reserve(trunk3_dump_bytes(e->num_cu));
     e->d_edge4.reserve((size_t)max_bases * 2 * C4_CH * sizeof(float));
     e->d_e4row.reserve((size_t)max_bases * sizeof(int32_t));
+    if (e->tail_impl == 3 && e->precision == 1 && (ctx_mask >> CHH & 1)) {   // strip tail: sized for the largest group, before anything is queued
+        e->d_mark.reserve(tail_strip_mark_bytes(2 * max_rows));
+        e->d_ccnt.reserve(tail_strip_count_bytes(2 * max_rows));
+        e->d_order.reserve((size_t)max_bases * sizeof(int32_t));
+        e->d_okey.reserve((size_t)max_bases * sizeof(int32_t));
+    }
     if (!e->d_zeros.p) {
         e->d_zeros.reserve(1024);
         HIP_TRY(hipMemsetAsync(e->d_zeros.p, 0, 1024, e->stream));
@@ -677,11 +683,6 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
                                           b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu);
                     }
                 } else if (e->tail_impl == 3 && e->precision == 1 && c == CHH) {   // (precision 2's fp16-weight layers live in tail_kernel_r)
-                    const int64_t vrows = g.rows * n_views;
-                    e->d_mark.reserve(tail_strip_mark_bytes(vrows));
-                    e->d_ccnt.reserve(tail_strip_count_bytes(vrows));
-                    e->d_order.reserve((size_t)max_bases * sizeof(int32_t));
-                    e->d_okey.reserve((size_t)max_bases * sizeof(int32_t));
                     launch_tail_strip(e->stream, sr, dm.w, maps, n_views, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(), e->d_mark.as<int32_t>(),
                                       e->d_ccnt.as<int32_t>(), e->d_order.as<int32_t>(), e->d_okey.as<int32_t>(), b->d_logits.as<float>(),
                                       b->d_p.as<float>(), b->d_ml.as<uint8_t>(), b->d_totals.as<int32_t>() + 11, e->num_cu);
