@@ -114,11 +114,15 @@ def test_u16_kinetics_equal_reencoded_u8(oracle):
 @pytest.mark.parametrize("ctx", ["CpG", "CHG", "CHH"])
 def test_cnn_matches_reference_torchscript(oracle, ctx):
     # CpG / CHH: outputs of the reference's TorchScript models; CHG: models/CHG.onnx evaluated with torch functional ops
-    # over an independent minimal ONNX parse (CHG.pt holds another checkpoint) -- tools/make_golden.py:make_cnn_chg
+    # over an independent minimal ONNX parse (CHG.pt holds another checkpoint) AND, since round 5, by the reference's own TorchScript
+    # graph (models/CpG.pt: the same architecture) with CHG.onnx's tensors in the place of its constants (`logits_ts`) --
+    # tools/make_golden.py:make_cnn_chg
     z = np.load(os.path.join(GOLDEN, f"cnn_{ctx}.npz"))
     m = oracle.Model(os.path.join(WEIGHTS, ctx + ".hmw"))
     lg = m.logits(z["windows"])
     assert np.abs(lg - z["logits"]).max() < 2e-5
+    if ctx == "CHG":
+        assert np.abs(z["logits_ts"] - z["logits"]).max() < 1e-5 and np.abs(lg - z["logits_ts"]).max() < 2e-5
     p, ml = oracle.softmax(lg)
     pr, _ = oracle.softmax(z["logits"])
     assert np.abs(p - pr).max() < 1e-5

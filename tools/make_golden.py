@@ -300,16 +300,51 @@ def make_cnn_chg(wins):
                 raise SystemExit(f"CHG.onnx: unexpected op {op}")
     assert nconv == 8 and tuple(h.shape) == (len(x), 2)
     lg = h.numpy().astype(np.float32)
-    np.savez_compressed(os.path.join(GOLD, "cnn_CHG.npz"), windows=x, logits=lg)
+    # ... and EXECUTED BY THE REFERENCE'S OWN GRAPH (round 5): models/CpG.pt is the TorchScript export of the same architecture (first kernel
+    # 11, BN folded), its 24 weight tensors are prim::Constant nodes of its forward graph -- CHG.onnx's tensors are put in their place
+    # (batch_norm: weight, bias, mean, var; the eight conv1d; the two matmul / add pairs, Gemm's [out, in] weights transposed) and the
+    # reference's graph is run on the same windows.  What CHG.onnx CONTAINS still comes through a parser of ours (two independent ones agree);
+    # what is COMPUTED from it is now the reference's exported program, not a re-evaluation of ours.
+    ts = torch.jit.load(os.path.join(REF, "models", "CpG.pt"), map_location="cpu")
+    tconst = lambda n: [i.node() for i in n.inputs() if i.node().kind() == "prim::Constant" and i.type().kind() == "TensorType"]  # noqa: E731
+    o_bn = [ins for op, ins, _ in nodes if op == "BatchNormalization"][0]
+    o_conv = [ins for op, ins, _ in nodes if op == "Conv"]
+    o_gemm = [ins for op, ins, _ in nodes if op == "Gemm"]
+    ci = gi = 0
+    for n in ts.graph.nodes():
+        if n.kind() == "aten::batch_norm":
+            for c, name in zip(tconst(n), (o_bn[1], o_bn[2], o_bn[3], o_bn[4])):
+                c.t_("value", T[name].clone())
+        elif n.kind() == "aten::conv1d":
+            c = tconst(n)
+            assert tuple(c[0].t("value").shape) == tuple(T[o_conv[ci][1]].shape)
+            c[0].t_("value", T[o_conv[ci][1]].clone())
+            c[1].t_("value", T[o_conv[ci][2]].clone())
+            ci += 1
+        elif n.kind() == "aten::matmul":
+            tconst(n)[0].t_("value", T[o_gemm[gi][1]].t().contiguous().clone())
+        elif n.kind() == "aten::add" and tconst(n):
+            tconst(n)[0].t_("value", T[o_gemm[gi][2]].clone())
+            gi += 1
+    assert ci == 8 and gi == 2
+    with torch.no_grad():
+        lg_ts = ts(torch.from_numpy(x)).numpy().astype(np.float32)
+    d_ts = float(np.abs(lg_ts - lg).max())
+    assert d_ts < 1e-5, d_ts
+    np.savez_compressed(os.path.join(GOLD, "cnn_CHG.npz"), windows=x, logits=lg, logits_ts=lg_ts)
     om = O.Model(os.path.join(ROOT, "hifimeth_amd", "weights", "CHG.hmw"))
     d = float(np.abs(om.logits(x) - lg).max())
     rp = os.path.join(GOLD, "cnn_report.json")
     report = json.load(open(rp)) if os.path.exists(rp) else {}
     report["CHG.onnx_torch_functional_over_independent_mini_parse_vs_oracle_max_dlogit"] = d
-    report["CHG_fixture_source"] = ("models/CHG.onnx evaluated with torch functional ops over tools/make_golden.py:_mini_onnx "
-                                    "(second, minimal ONNX parse); CHG.pt is a different checkpoint and was not used")
+    report["CHG.onnx_weights_run_by_the_reference_TorchScript_graph_vs_torch_functional_max_dlogit"] = d_ts
+    report["CHG.onnx_weights_run_by_the_reference_TorchScript_graph_vs_oracle_max_dlogit"] = float(np.abs(om.logits(x) - lg_ts).max())
+    report["CHG_fixture_source"] = ("models/CHG.onnx evaluated (a) with torch functional ops over tools/make_golden.py:_mini_onnx (second, minimal ONNX "
+                                    "parse) and (b) by the REFERENCE'S OWN TorchScript graph -- models/CpG.pt, the same architecture -- with CHG.onnx's "
+                                    "tensors put in the place of its 24 constants (`logits_ts`); CHG.pt is a different checkpoint and was not used")
     json.dump(report, open(rp, "w"), indent=1)
-    print(f"cnn_CHG.npz: {len(x)} windows, oracle(ONNX weights) vs torch-functional(CHG.onnx, mini parse) max |dlogit| = {d:.3g}")
+    print(f"cnn_CHG.npz: {len(x)} windows, oracle(ONNX weights) vs torch-functional(CHG.onnx, mini parse) max |dlogit| = {d:.3g}; "
+          f"the reference's TorchScript graph over CHG.onnx's weights vs torch-functional: {d_ts:.3g}")
 
 
 def make_config_goldens():
