@@ -746,6 +746,18 @@ def test_strip_tail_is_byte_identical_to_the_resident_tail():
                 out.append(m.call(rs[::-1]).copy())      # a second, different batch through the same engine (buffers reused)
         assert len(out[0]) == len(out[2]) > 50, (spec, len(out[0]))
         assert out[0].tobytes() == out[2].tobytes() and out[1].tobytes() == out[3].tobytes(), (spec, group_bases, ncu)
+    # site densities from sparse to dense (GC 0.2 ... 0.7: CHH 0.16 ... 0.27 sites per base; the strip holds 11 ... 16 sites per pass) and
+    # CpG-depleted, human-like reads: passes of every fill, classes that run dry inside a strip
+    from hifimeth_amd.synth import synth_slab
+    for gc, oe in ((0.2, 1.0), (0.5, 1.0), (0.7, 1.0), (0.41, 0.24)):
+        rs = synth_slab(6, seed=int(1000 * gc), gc=gc, cpg_oe=oe, median_len=9000, sigma=0.5, frac_wide=0.2)
+        out = []
+        for impl in (1, 3):
+            with MethylationCaller(contexts="chh", device=0) as m:
+                m.set_option("trunk", 1)
+                m.set_option("tail_impl", impl)
+                out.append(m.call(rs).copy())
+        assert len(out[0]) > 5000 and out[0].tobytes() == out[1].tobytes(), (gc, oe)
 
 
 @pytest.mark.gpu
