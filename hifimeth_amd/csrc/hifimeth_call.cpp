@@ -425,6 +425,11 @@ int cmd_call(int argc, char** argv) {
         return o.help ? 0 : EXIT_FAILURE;  // -h / -v exit 0 like the reference (mod_options.cpp:62-71)
     }
     const auto t0 = std::chrono::steady_clock::now();
+    // HM_CLI_TIMING=1: where the command's fixed costs go (seconds since start, on stderr)
+    const bool clk_on = getenv("HM_CLI_TIMING") != nullptr;
+    auto clk = [&](const char* what) {
+        if (clk_on) fprintf(stderr, "[%s] t=%.3f s: %s\n", kName, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what);
+    };
     if (o.ld_out) bam_use_libdeflate_compress(true);
     BgzfReader in(o.in, o.threads);
     if (!in.ok()) { fprintf(stderr, "[%s] %s\n", kName, in.error().c_str()); return EXIT_FAILURE; }
@@ -454,6 +459,7 @@ int cmd_call(int argc, char** argv) {
         if (tmask < 0) { fprintf(stderr, "[%s] %s: %s\n", kName, o.in.c_str(), err.c_str()); return EXIT_FAILURE; }
         for (auto* e : eng) hm_set_option(e, "trunk_mask", tmask);
     }
+    clk("engines created, kernel paths chosen from the head of the input");
     size_t all_reads = 0, all_bases = 0, all_ctx[3] = {0, 0, 0}, all_parts = 0;
     std::atomic<bool> failed{false};
 
@@ -532,6 +538,7 @@ int cmd_call(int argc, char** argv) {
             all_bases += (size_t)jb.recs[i].l_qseq();
             write_record(*out, jb.recs[i]);
         }
+        if (all_reads == 0) clk("first slab called, tagged and written");
         all_reads += jb.recs.size();
         fprintf(stderr, "[%s] %zu reads done\n", kName, all_reads);
     };
@@ -562,7 +569,12 @@ int cmd_call(int argc, char** argv) {
         cv.notify_all();
     };
     auto launch = [&](Job&& jb) {
-        if (hm_batch_enqueue(jb.batch) < 0) {
+        static std::atomic<int> n_launch{0};
+        const int my_launch = n_launch++;
+        if (my_launch == 0) clk("first slab read, parsed and staged");
+        const int rc_enq = hm_batch_enqueue(jb.batch);
+        if (my_launch == 0) clk("first slab queued on the device (group buffers allocated)");
+        if (rc_enq < 0) {
             fprintf(stderr, "[%s] %s\n", kName, hm_last_error(eng[jb.dev]));
             failed = true;
             hm_batch_release(jb.batch);
@@ -653,9 +665,12 @@ int cmd_call(int argc, char** argv) {
         no_more = true;
     }
     cv.notify_all();
+    clk("last slab queued");
     writer.join();
     close_out();
+    clk("output closed");
     for (auto* e : eng) hm_destroy(e);
+    clk("engines destroyed");
     if (failed) return EXIT_FAILURE;
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "******** Final stats:\n  ## Reads: %zu\n  ## Bases: %zu\n", all_reads, all_bases);
