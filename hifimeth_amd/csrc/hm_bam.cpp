@@ -7,7 +7,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cctype>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <unordered_set>
 
@@ -50,7 +53,8 @@ const LibDeflate& libdeflate() {
     static const LibDeflate ld;
     return ld;
 }
-// one decompressor / compressor per thread (they are not thread-safe, and allocating one per 64 KB block costs more than the block)
+// one decompressor / compressor per pool worker, for the life of the process (they are not thread-safe, and allocating one per
+// 64 KB block costs more than the block)
 struct TlsD {
     void* d = nullptr;
     ~TlsD() { if (d) libdeflate().free_d(d); }
@@ -98,20 +102,84 @@ namespace hmbam {
 
 namespace {
 
+// Worker pool of the process (advisor r4 #4): parallel_for used to start `threads` std::threads per call -- once per 256-block BGZF
+// batch, per record batch, per output flush -- so every thread_local (de)compressor lived for one batch.  The workers below are
+// started on first need, grow to the largest `threads` any caller asked for and live until the process ends (the pool object is
+// never destroyed: no join order to get wrong against the HIP runtime's own exit handlers), so a worker's libdeflate state is
+// allocated once.  Several callers may have a job open at the same time (the reader's prefetch inflates while the writer deflates and
+// the tag builder runs): workers take items from the oldest job that still has any, at most `threads` of them on one job.  The caller
+// only waits; a call made from inside a worker runs its items inline (no nesting deadlock).
+class Pool {
+  public:
+    static Pool& get() {
+        static Pool* p = new Pool;
+        return *p;
+    }
+    void run(int n, int threads, const std::function<void(int)>& f) {
+        threads = std::max(1, std::min(threads, n));
+        if (threads == 1 || in_worker_) {
+            for (int i = 0; i < n; ++i) f(i);
+            return;
+        }
+        Job job;
+        job.f = &f;
+        job.n = n;
+        job.cap = threads;
+        std::unique_lock<std::mutex> lk(mu_);
+        while ((int)workers_.size() < std::min(threads, kMaxWorkers)) workers_.emplace_back([this] { work(); });
+        jobs_.push_back(&job);
+        cv_.notify_all();
+        job.cv_done.wait(lk, [&] { return job.done == job.n; });
+        jobs_.erase(std::find(jobs_.begin(), jobs_.end(), &job));
+    }
+
+  private:
+    struct Job {
+        const std::function<void(int)>* f = nullptr;
+        int n = 0, cap = 0;
+        int next = 0, done = 0, active = 0;  // all under mu_
+        std::condition_variable cv_done;
+    };
+    static constexpr int kMaxWorkers = 256;
+    static thread_local bool in_worker_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<Job*> jobs_;  // oldest first
+    std::vector<std::thread> workers_;
+
+    Job* pick() {
+        for (Job* j : jobs_)
+            if (j->next < j->n && j->active < j->cap) return j;
+        return nullptr;
+    }
+    void work() {
+        in_worker_ = true;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            Job* j = nullptr;
+            cv_.wait(lk, [&] { return (j = pick()) != nullptr; });
+            ++j->active;
+            // a few items per lock round trip when there are many (records), one when there are few (blocks, slices)
+            while (j->next < j->n) {
+                const int a = j->next, b = std::min(j->n, a + std::max(1, j->n / (j->cap * 16)));
+                j->next = b;
+                lk.unlock();
+                for (int i = a; i < b; ++i) (*j->f)(i);
+                lk.lock();
+                j->done += b - a;
+            }
+            --j->active;
+            if (j->done == j->n) j->cv_done.notify_one();
+        }
+    }
+};
+thread_local bool Pool::in_worker_ = false;
+
 template <class F>
 void parallel_for(int n, int threads, F f) {
-    threads = std::max(1, std::min(threads, n));
-    if (threads == 1) {
-        for (int i = 0; i < n; ++i) f(i);
-        return;
-    }
-    std::atomic<int> next{0};
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads; ++t)
-        pool.emplace_back([&] {
-            for (int i = next++; i < n; i = next++) f(i);
-        });
-    for (auto& t : pool) t.join();
+    if (n <= 0) return;
+    const std::function<void(int)> fn = std::ref(f);
+    Pool::get().run(n, threads, fn);
 }
 
 inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
