@@ -579,12 +579,16 @@ def main():
             edge_mfma = sum(served[c] / 32.0 * edge_pass[k1[c]] for c in range(3))
             # tail_kernel_r, per pass of 8 sites: conv5 7 m-tiles x 6 x 9 x 3, conv6 4 x 6 x 9 x 3, conv7 2 x 4 x 9 x 3, conv8 1 x 4 x 6 x 3, fc1 per
             # 32 sites 2 x 16 x 4 x 3.  tail_kernel_p (strip tail, CHH), per pass of 16 site slots, zero-padding taps skipped: conv5 (13 x 9 - 6)
-            # k-blocks x 3 x 6, conv6 (7 x 9 - 6) x 3 x 6, conv7 (4 x 9 - 6) x 3 x 4, conv8 (2 x 6 - 2) x 3 x 4, fc1 16 x 4 x 3; the kernel counts its passes
+            # k-blocks x 3 x 6, conv6 (7 x 9 - 6) x 3 x 6, conv7 (4 x 9 - 6) x 3 x 4, conv8 (2 x 6 - 2) x 3 x 4; the kernel counts its passes.  fc1 of those
+            # sites runs in tail_fc_kernel on full tiles of 16 sites in list order: 16 n-tiles x 4 k-blocks x 3 per tile (the ragged last tile of a
+            # launch -- one in ~ 160 000 -- is not counted)
             pr8 = 2 if args.precision == 2 else 3   # products per k-block in conv8 and fc1 (precision 2: plain fp16 weights there)
             tail_r_site = (7 * 6 * 27 + 4 * 6 * 27 + 2 * 4 * 27 + 4 * 6 * pr8) / 8.0 + 2 * 16 * 4 * pr8 / 32.0
-            strip_pass = (13 * 9 - 6) * 18 + (7 * 9 - 6) * 18 + (4 * 9 - 6) * 12 + (2 * 6 - 2) * 4 * pr8 + 16 * 4 * pr8
+            strip_pass = (13 * 9 - 6) * 18 + (7 * 9 - 6) * 18 + (4 * 9 - 6) * 12 + (2 * 6 - 2) * 4 * pr8
+            fc_tile = 16 * 4 * pr8
             strip_passes = int(tm.get("tail_strip_passes", 0))
-            tail_mfma = sum(served[c] * tail_r_site for c in range(3) if not (c == 2 and strip_passes > 0)) + strip_passes * strip_pass
+            strip_mfma = strip_passes * strip_pass + (served[2] / 16.0 * fc_tile if strip_passes > 0 else 0.0)
+            tail_mfma = sum(served[c] * tail_r_site for c in range(3) if not (c == 2 and strip_passes > 0)) + strip_mfma
             edge_ms_t, tail_ms_t = sum(tm["edge_ms"]), sum(tm["tail_ms"])
             tf = lambda n, ms: n * 16384.0 / (ms * 1e-3) / 1e12 if ms > 0 else 0.0  # noqa: E731
             dev_ms = trunk_ms + edge_ms_t + tail_ms_t
@@ -594,8 +598,8 @@ def main():
                          "mfma_per_site": {"K1=11": edge_pass[11] / 32.0, "K1=13": edge_pass[13] / 32.0}},
                 "tail": {"mfma": tail_mfma, "ms": tail_ms_t, "executed": tf(tail_mfma, tail_ms_t), "frac": tf(tail_mfma, tail_ms_t) / peak, "share_of_device_ms": tail_ms_t / dev_ms,
                          "strip_tail_passes": strip_passes, "strip_tail_sites_per_pass": served[2] / strip_passes if strip_passes else None,
-                         "mfma_per_site": {"tail_kernel_r": tail_r_site, "tail_kernel_p": strip_pass * strip_passes / served[2] if strip_passes and served[2] else None},
-                         "note": "tail_ms of the strip tail includes its class sort (memset + 4 small kernels per launch)"},
+                         "mfma_per_site": {"tail_kernel_r": tail_r_site, "tail_kernel_p + tail_fc_kernel": strip_mfma / served[2] if strip_passes and served[2] else None},
+                         "note": "tail_ms of the strip tail = its class sort (memset + 4 small kernels per launch) + tail_kernel_p (conv5 .. conv8) + tail_fc_kernel (fc1, fc2, softmax)"},
                 # this rank's device: all MFMAs of the timed region over its WALL time (copies, staging and scanner kernels included)
                 "whole_device": {"mfma": n_mfma + edge_mfma + tail_mfma, "executed_over_timed_region": tf(n_mfma + edge_mfma + tail_mfma, dt * 1e3),
                                  "frac_over_timed_region": tf(n_mfma + edge_mfma + tail_mfma, dt * 1e3) / peak},

@@ -57,6 +57,19 @@ struct EpiP {
         *reinterpret_cast<half4*>(lo + TILE * 16 * ORS + col) = s.l;
     }
 };
+// conv8's rows on their way to tail_fc_kernel (hm_tail_fc.hip): ReLU + split -> global, a site's 512 bytes = [hi: position * 64 + channel | lo];
+// `g` is this lane's: x8 + (the site's list position) * TAIL_X8_HALVES + 4 * lk
+struct EpiX8 {
+    static constexpr int NV0 = 6, NV1 = 1, NW = 2, WMASK = 0x040;
+    struct St { half4 h, l; };
+    half_t* g;
+    __device__ __forceinline__ void s0(const f32x4& acc, St& s) const { split4(acc, s.h, s.l); }
+    template <int TILE>
+    __device__ __forceinline__ void s1(int col, const St& s) const {
+        *reinterpret_cast<half4*>(g + TILE * 64 + col) = s.h;
+        *reinterpret_cast<half4*>(g + TAIL_X8_HALVES / 2 + TILE * 64 + col) = s.l;
+    }
+};
 // fc1: ReLU, fp32 h[site][8 parts of 32, HPS floats apart] for the VALU fc2; `out` is this lane's: h + li * (8 HPS) + 4 * lk
 template <int HPS>
 struct EpiFc1P {

@@ -130,6 +130,7 @@ struct CtxWeights {
 constexpr int C4_LEN = 25, C4_CH = 96;          // conv4 output = hand-off between front and tail kernels
 constexpr int ACT4_FLOATS = C4_LEN * C4_CH;      // 2400 floats / site
 constexpr int TAIL_SITES = 8;                    // sites stacked along M in the tail kernel
+constexpr int TAIL_X8_HALVES = 256;              // conv8's output of a site on its way to tail_fc_kernel: [hi: 2 positions x 64 channels | lo] (hm_tail_fc.hip)
 constexpr int TAILP_STRIP = 144;                 // strip tail (hm_tail_p.hip): lattice rows (16 map rows apart) of E4 a pass of 16 sites shares in LDS
 
 }  // namespace hm

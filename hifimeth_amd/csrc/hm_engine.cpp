@@ -204,6 +204,8 @@ struct hm_engine {
     DevBuf d_map[3], d_e4, d_edge4, d_e4row, d_zeros, d_rowlist;  // dense trunk: maps of one read group, edge rows of its sites
     DevBuf d_x6;                // split tail: conv6's rows of one launch (hm_tail_s.hip)
     DevBuf d_mark, d_ccnt, d_order, d_okey;  // strip tail (hm_tail_p.hip): per-map-row marks, class counters, the class-sorted site order and its keys
+    DevBuf d_odst;              // strip tail: list position -> the site's slot in the batch's result arrays (tail_fc_kernel's stores)
+    DevBuf d_x8;                // conv8's rows of a launch's sites on their way from the strip tail kernel to tail_fc_kernel (512 B per site)
     DevBuf d_dump;              // sliding-window trunk: where a warm-up step's conv4 rows go (hm_trunk3.hip)
     int64_t x6_sites = 0;       // the site count d_x6's plane stride was laid out for
 
@@ -215,7 +217,8 @@ namespace {
 
 // Device bytes per base of a read group: E1..E3 maps (2 views x 512 B each), E4 (2 x 384 B), the sites' edge rows (768 B) and map-row
 // numbers, row lists -- times the 25 % head-room DevBuf::reserve adds.
-constexpr int64_t GROUP_BYTES_PER_BASE = (3 * 2 * 512 + 2 * 384 + 768 + 4 + 8 + 2 * 4 + 8) * 5 / 4;  // (+ the strip tail's marks per map row and its sorted order)
+constexpr int64_t GROUP_BYTES_PER_BASE = (3 * 2 * 512 + 2 * 384 + 768 + 4 + 8 + 2 * 4 + 8 + 4 + 512) * 5 / 4;  // (+ the strip tail's marks per map row, its sorted order and
+                                                                                                            //  conv8's rows for tail_fc_kernel, sized per base: a base is at most one site)
 
 int64_t effective_group_bases(hm_engine* e) {
     if (e->group_bases > 0) return e->group_bases;
@@ -601,6 +604,8 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
         e->d_ccnt.reserve(tail_strip_count_bytes(2 * max_rows));
         e->d_order.reserve((size_t)max_bases * sizeof(int32_t));
         e->d_okey.reserve((size_t)max_bases * sizeof(int32_t));
+        e->d_odst.reserve((size_t)max_bases * sizeof(int32_t));
+        e->d_x8.reserve(tail_fc_x8_bytes(max_bases));
     }
     if (!e->d_zeros.p) {
         e->d_zeros.reserve(1024);
@@ -684,8 +689,8 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
                     }
                 } else if (e->tail_impl == 3 && e->precision == 1 && c == CHH) {   // (precision 2's fp16-weight layers live in tail_kernel_r)
                     launch_tail_strip(e->stream, sr, dm.w, maps, n_views, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(), e->d_mark.as<int32_t>(),
-                                      e->d_ccnt.as<int32_t>(), e->d_order.as<int32_t>(), e->d_okey.as<int32_t>(), b->d_logits.as<float>(),
-                                      b->d_p.as<float>(), b->d_ml.as<uint8_t>(), b->d_totals.as<int32_t>() + 11, e->num_cu);
+                                      e->d_ccnt.as<int32_t>(), e->d_order.as<int32_t>(), e->d_okey.as<int32_t>(), e->d_odst.as<int32_t>(), e->d_x8.as<uint16_t>(),
+                                      b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), b->d_totals.as<int32_t>() + 11, e->num_cu);
                 } else if ((e->tail_impl == 1 || e->tail_impl == 3) && e->precision >= 1)
                     launch_tail_gather_r(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
                                          b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu, e->precision == 2);
@@ -905,7 +910,7 @@ void hm_destroy(hm_engine_t* e) {
     e->slots.clear();
     for (auto& m : e->model) m.params.release();
     for (DevBuf* b : {&e->d_act4, &e->d_win, &e->d_dbg, &e->d_stamps, &e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4, &e->d_rowlist,
-                      &e->d_edge4, &e->d_e4row, &e->d_zeros, &e->d_x6, &e->d_dump, &e->d_mark, &e->d_ccnt, &e->d_order, &e->d_okey})
+                      &e->d_edge4, &e->d_e4row, &e->d_zeros, &e->d_x6, &e->d_dump, &e->d_mark, &e->d_ccnt, &e->d_order, &e->d_okey, &e->d_odst, &e->d_x8})
         b->release();
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1425,7 +1430,7 @@ int hm_get_timing(hm_engine_t* e, hm_timing_t* t) {
     *t = e->acc;
     t->group_bases = effective_group_bases(e);  // (sized from free device memory now if no read has been staged yet)
     t->group_bytes = 0;
-    for (const DevBuf* d : {&e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4, &e->d_rowlist, &e->d_edge4, &e->d_e4row, &e->d_x6, &e->d_dump, &e->d_mark, &e->d_ccnt, &e->d_order, &e->d_okey})
+    for (const DevBuf* d : {&e->d_map[0], &e->d_map[1], &e->d_map[2], &e->d_e4, &e->d_rowlist, &e->d_edge4, &e->d_e4row, &e->d_x6, &e->d_dump, &e->d_mark, &e->d_ccnt, &e->d_order, &e->d_okey, &e->d_odst, &e->d_x8})
         t->group_bytes += (int64_t)d->cap;
     return HM_OK;
 }

@@ -44,6 +44,11 @@ namespace hm {
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void tail_kernel_p(HM_TAILP_PARAMS) {
+#ifdef HM_TAILP_FC_IN_KERNEL
+    constexpr bool FC_IN_KERNEL = true;    // A/B build (make HM_TAILP_FC_IN_KERNEL=1): fc1, fc2, softmax per pass, as before the split
+#else
+    constexpr bool FC_IN_KERNEL = false;   // the pass ends with conv8; fc1 .. softmax: tail_fc_kernel (hm_tail_fc.hip)
+#endif
     constexpr bool W16 = false;   // (plain fp16 weights in conv8 / fc1 -- engine option precision = 2 -- run on tail_kernel_r<true>: a second
                                   //  instance of THIS kernel, in this file or in one of its own, spilled 9 - 13 registers in one of the two)
 #include "hm_tail_p_body.inc"
@@ -116,8 +121,11 @@ __global__ __launch_bounds__(1024) void class_scan_kernel(int32_t* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void class_write_kernel(const int32_t* __restrict__ mark, int64_t n_rows, int n_blocks, const int32_t* __restrict__ offs,
-                                                          int32_t* __restrict__ order, int32_t* __restrict__ okey) {
+// (odst[o]: the site's slot in the batch's result arrays, for tail_fc_kernel)
+__global__ __launch_bounds__(256) void class_write_kernel(SiteRange sr, const int32_t* __restrict__ mark, int64_t n_rows, int n_blocks, const int32_t* __restrict__ offs,
+                                                          int32_t* __restrict__ order, int32_t* __restrict__ okey, int32_t* __restrict__ odst) {
+    const Site* sites;
+    const int n_sites = resolve_sites(sr, sites);
     __shared__ int32_t wc[4][16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int32_t m[16];
@@ -138,6 +146,7 @@ __global__ __launch_bounds__(256) void class_write_kernel(const int32_t* __restr
         for (int w = 0; w < wave; ++w) o += wc[w][c];
         order[o] = m[c];
         okey[o] = (int32_t)(row0 + c);
+        odst[o] = sites ? sites[min(max(m[c], 0), max(n_sites, 1) - 1)].uidx : m[c];
     }
 }
 
@@ -145,8 +154,8 @@ size_t tail_strip_mark_bytes(int64_t map_rows) { return (size_t)(map_rows + CS_R
 size_t tail_strip_count_bytes(int64_t map_rows) { return (size_t)16 * (size_t)((map_rows + CS_ROWS - 1) / CS_ROWS + 1) * sizeof(int32_t); }
 
 void launch_tail_strip(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, int n_views, const uint16_t* edge4,
-                       const int32_t* e4row, int32_t* mark, int32_t* cnt, int32_t* order, int32_t* okey, float* logits, float* p, uint8_t* ml,
-                       int32_t* pass_count, int grid) {
+                       const int32_t* e4row, int32_t* mark, int32_t* cnt, int32_t* order, int32_t* okey, int32_t* odst, uint16_t* x8, float* logits,
+                       float* p, uint8_t* ml, int32_t* pass_count, int grid) {
     if (sr.cap <= 0) return;
     const int64_t n_rows = maps.view_rows * n_views;
     const int n_blocks = (int)((n_rows + CS_ROWS - 1) / CS_ROWS);
@@ -154,10 +163,14 @@ void launch_tail_strip(hipStream_t st, const SiteRange& sr, const CtxWeights& w,
     hipLaunchKernelGGL(class_mark_kernel, dim3(max(1, min((sr.cap + 255) / 256, 4 * grid))), dim3(256), 0, st, sr, e4row, mark);
     hipLaunchKernelGGL(class_count_kernel, dim3(n_blocks), dim3(256), 0, st, mark, n_rows, n_blocks, cnt);
     hipLaunchKernelGGL(class_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, 16 * n_blocks);
-    hipLaunchKernelGGL(class_write_kernel, dim3(n_blocks), dim3(256), 0, st, mark, n_rows, n_blocks, cnt, order, okey);
+    hipLaunchKernelGGL(class_write_kernel, dim3(n_blocks), dim3(256), 0, st, sr, mark, n_rows, n_blocks, cnt, order, okey, odst);
     const dim3 g(sr.totals ? grid : max(1, min((sr.cap + PGeo::S - 1) / PGeo::S, grid)));
     hipLaunchKernelGGL(tail_kernel_p, g, dim3(256), 0, st, sr, w, logits, p, ml, reinterpret_cast<const half_t*>(maps.e4),
-                            reinterpret_cast<const half_t*>(edge4), order, okey, (int)std::min<int64_t>(n_rows, INT32_MAX), pass_count);
+                            reinterpret_cast<const half_t*>(edge4), order, okey, (int)std::min<int64_t>(n_rows, INT32_MAX), pass_count,
+                            reinterpret_cast<half_t*>(x8));
+#ifndef HM_TAILP_FC_IN_KERNEL
+    launch_tail_fc(st, sr, w, x8, odst, logits, p, ml, grid);
+#endif
 }
 
 }  // namespace hm

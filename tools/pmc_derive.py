@@ -23,7 +23,7 @@ for k, c in sorted(d.items()):
     gui, mf = g("GRBM_GUI_ACTIVE"), g("SQ_INSTS_MFMA")
     wc = max(g("SQ_WAVE_CYCLES"), 1.0)
     k = k.replace("void hm::", "")
-    k = "tail_kernel_r (resident weights)" if k == "tail_kernel_r" else "tail_kernel_p (strip tail, CHH)" if k == "tail_kernel_p" else k
+    k = "tail_kernel_r (resident weights)" if k == "tail_kernel_r" else "tail_kernel_p (strip tail, CHH)" if k == "tail_kernel_p" else "tail_fc_kernel (fc1 .. softmax, CHH)" if k == "tail_fc_kernel" else k
     print(f"{k:36s} launches {c['GRBM_GUI_ACTIVE'][1]:4d}  mean launch {gui / 8 / 2.1e6:7.3f} ms(@2.1GHz)  "
           f"MFMA busy {g('SQ_VALU_MFMA_BUSY_CYCLES') / (gui / 8 * 1024):.3f}  MFMA/launch {mf:.3g}  VALU/MFMA {g('SQ_INSTS_VALU') / mf:.2f}  "
           f"LDS/MFMA {g('SQ_INSTS_LDS') / mf:.2f}  VMEM_RD/MFMA {g('SQ_INSTS_VMEM_RD') / mf:.2f}  "

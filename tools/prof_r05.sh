@@ -38,7 +38,7 @@ for f in sorted(glob.glob("$O/pmc/g*/**/*counter_collection.csv", recursive=True
     for row in csv.DictReader(open(f)):
         n = row["Kernel_Name"]
         k = n.split("(")[0].split("<")[0][-28:] + ("<13" if "<13" in n or "ILi13" in n else "")
-        for t in ("tail_kernel_p", "class_count_kernel", "class_write_kernel", "class_mark_kernel", "class_scan_kernel", "tail_kernel_r", "tail_main_kernel", "tail_head_kernel", "trunk3_kernel", "trunk2_kernel", "rowlist3_kernel", "edge2_kernel"):
+        for t in ("tail_kernel_p", "tail_fc_kernel", "class_count_kernel", "class_write_kernel", "class_mark_kernel", "class_scan_kernel", "tail_kernel_r", "tail_main_kernel", "tail_head_kernel", "trunk3_kernel", "trunk2_kernel", "rowlist3_kernel", "edge2_kernel"):
             if t in n:
                 k = t + ("<13>" if ("<13" in n or "ILi13" in n) else "<11>" if ("<11" in n or "ILi11" in n) else "")
         a = agg[(k, row["Counter_Name"])]

@@ -32,7 +32,7 @@ for impl in (3, 1):
     tm = mc.timing()
     if impl == 3:
         print(f"tail_kernel_p: passes of workgroup 0: {int(n)}, sites taken {int(buf[0, 12])} = {float(buf[0, 12]) / max(n, 1):.2f} per pass of 16 slots; CHH sites {mc.num_sites(2)}")
-        names = ["plan + conv5", "barrier", "conv6 (+early DMA)", "barrier", "conv7", "drain + barrier", "late DMA + conv8", "fc loads + barrier", "fc1", "fc2 + softmax"]
+        names = ["plan + conv5", "barrier", "conv6 (+early DMA)", "barrier", "conv7", "drain + barrier", "late DMA + conv8", "fc loads + barrier", "fc1", "fc2 + softmax"]   # (the last three: 0 since fc1 .. softmax left for tail_fc_kernel)
         tot = np.zeros(4)
         for i, nm in enumerate(names):
             v = buf[:, i].astype(float) / n
@@ -40,6 +40,7 @@ for impl in (3, 1):
             print(f"{nm:30s} " + " ".join(f"{x:7.0f}" for x in v))
         print(f"{'sum (ticks per pass)':30s} " + " ".join(f"{x:7.0f}" for x in tot))
         print(f"{'ticks per site':30s} " + " ".join(f"{x * n / max(float(buf[0, 12]), 1):7.0f}" for x in tot))
+        print(f"{'whole loop, ticks per pass':30s} " + " ".join(f"{float(x) / n:7.0f}" for x in buf[:, 13]) + "   (with the drain and the wait at the loop's top barrier, which no phase above holds)")
     else:
         tot = buf[:, :10].astype(float).sum(axis=1) / n
         print(f"tail_kernel_r: passes of workgroup 0: {int(n)} (8 sites each); ticks per pass " + " ".join(f"{x:7.0f}" for x in tot)
