@@ -1,5 +1,6 @@
-// hm_tail_p.hip -- the STRIP tail kernel: conv5 .. conv8, fc1, fc2, softmax of the dense-trunk path for a context whose sites are
-// DENSE (CHH: one view position in eight is a site), 16 sites per workgroup pass instead of tail_kernel_r's 8.
+// hm_tail_p.hip -- the STRIP tail kernel: conv5 .. conv8 of the dense-trunk path for a context whose sites are DENSE (CHH: one view
+// position in eight is a site), 16 sites per workgroup pass instead of tail_kernel_r's 8.  fc1, fc2 and the softmax of those sites run
+// behind it in tail_fc_kernel (hm_tail_fc.hip), which this file's launcher starts; conv8's rows travel through x8 (512 B per site).
 //
 // What a site reads.  Its 25 conv4 rows are two rows of its own (the window-edge rows, edge kernel) and 23 rows of the dense E4
 // map, 16 map rows apart: e4row + 16 s, s = 1 .. 23 (hm_device.h).  Two sites of one strand view whose first map rows agree
@@ -18,8 +19,8 @@
 // accumulator as tail_kernel_r: byte-identical calls (tests/test_gpu_parity.py).
 //
 // LDS (159.3 KB): A = [strip 144 rows | edge row 0 of 16 sites | edge row 24 of 16 sites] x (hi, lo) planes of 208-byte rows;
-// B = conv5's output [13][16 sites] x (hi, lo).  conv6's output overlays the strip (rows 0 .. 111), conv7's, conv8's and fc1's
-// outputs overlay B.  The next pass's gather (LDS-DMA, row-aligned quads as in hm_tail_r.hip; the strip's source rows are
+// B = conv5's output [13][16 sites] x (hi, lo).  conv6's output overlays the strip (rows 0 .. 111), conv7's overlays B (and conv8's
+// and fc1's in the build that keeps fc1 .. softmax in the pass: make fcin).  The next pass's gather (LDS-DMA, row-aligned quads as in hm_tail_r.hip; the strip's source rows are
 // equidistant, no address table) runs in two parts: the edge rows and strip rows 112 .. 143 while conv6 / conv7 run, strip rows
 // 0 .. 111 once conv7 has read conv6's output -- their lines are pulled into L2 by touch loads while conv5 runs, so that the
 // late part is an L2 copy.
