@@ -100,25 +100,42 @@ __global__ __launch_bounds__(256) void class_count_kernel(const int32_t* __restr
     if (t < 16) cnt[(size_t)t * n_blocks + blockIdx.x] = wc[0][t] + wc[1][t] + wc[2][t] + wc[3][t];
 }
 
-// exclusive scan of n counters in place, one workgroup
+// exclusive scan of n counters in place, one workgroup of 16 waves: a wave owns a contiguous range, sums it (coalesced, 64 counters per
+// load), then rewrites it 256 counters per round -- four loads in flight, a wave-level inclusive scan (shuffles) each, the running sum
+// carried in a scalar.  (A thread per contiguous chunk -- the first form -- read with a 350-byte stride and one counter per round trip:
+// 146 us per launch for 90 k counters, more than the other three sort kernels together.)
 __global__ __launch_bounds__(1024) void class_scan_kernel(int32_t* __restrict__ cnt, int n) {
-    __shared__ int32_t part[1024];
-    const int t = threadIdx.x, per = (n + 1023) / 1024, lo = min(t * per, n), hi = min(lo + per, n);
+    __shared__ int32_t wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = ((n + 15) / 16 + 255) / 256 * 256;   // counters per wave: whole rounds of 256
+    const int lo = min(wave * per, n), hi = min(lo + per, n);
     int32_t s = 0;
-    for (int i = lo; i < hi; ++i) s += cnt[i];
-    part[t] = s;
+    for (int i = lo + lane; i < hi; i += 64) s += cnt[i];
+#pragma unroll
+    for (int d = 32; d; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) wsum[wave] = s;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const int32_t v = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    int32_t run = part[t] - s;
-    for (int i = lo; i < hi; ++i) {
-        const int32_t v = cnt[i];
-        cnt[i] = run;
-        run += v;
+    int32_t run = 0;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    for (int i0 = lo; i0 < hi; i0 += 256) {
+        int32_t v[4], x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 64 * k + lane;
+            v[k] = i < hi ? cnt[i] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            x[k] = v[k];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int32_t y = __shfl_up(x[k], d, 64);
+                if (lane >= d) x[k] += y;
+            }
+            const int i = i0 + 64 * k + lane;
+            if (i < hi) cnt[i] = run + x[k] - v[k];
+            run += __shfl(x[k], 63, 64);
+        }
     }
 }
 
