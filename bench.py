@@ -233,7 +233,9 @@ def free_port():
 
 def clean_env():
     """This process's environment without what a torchrun parent put there (a nested launch must build its own world)."""
-    return {k: v for k, v in os.environ.items() if k not in TORCHRUN_ENV}
+    env = {k: v for k, v in os.environ.items() if k not in TORCHRUN_ENV}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (this pool's driver supports dmabuf IPC only: RCCL needs it; already exported on the boxes)
+    return env
 
 
 def launch_ranks(n, argv):

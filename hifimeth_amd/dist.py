@@ -68,6 +68,9 @@ def init_process_group(backend: str | None = None, force: bool = False):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
+        # (this pool's host driver supports dmabuf IPC only; without the setting RCCL fails with `hipIpcGetMemHandle: invalid argument`.
+        #  It must be in the environment before the first HIP call of the process: the launchers export it, this is the last chance)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
