@@ -2,6 +2,16 @@
 #pragma once
 #include "hm_convp.h"
 
+// operand ring depth (half8 registers) and look-ahead (k-blocks) of conv5's / conv6's streams in the strip kernel
+#ifndef HM_TAILP_C5_NS
+#define HM_TAILP_C5_NS 8
+#define HM_TAILP_C5_LA 1
+#endif
+#ifndef HM_TAILP_C6_NS
+#define HM_TAILP_C6_NS 8
+#define HM_TAILP_C6_LA 1
+#endif
+
 namespace hm {
 
 namespace {
