@@ -761,6 +761,36 @@ def test_strip_tail_is_byte_identical_to_the_resident_tail():
 
 
 @pytest.mark.gpu
+def test_fc_kernel_tiles_of_16_with_ragged_ends():
+    """tail_fc_kernel (hm_tail_fc.hip) takes the class-sorted list in tiles of 16 positions, whatever pass a site was taken in: reads
+    built to hold EXACTLY k CHH sites (poly-A with k isolated C: no G, so nothing on the reverse strand) for k around the tile size --
+    one site, one short of a tile, a full tile, one more, two tiles and one -- give k calls, byte-identical to tail_kernel_r's, alone and
+    together in one batch (launches of 1 .. 82 sites: last tiles of every fill; the strip kernel's stand-in slots write nothing new)."""
+    from hifimeth_amd import MethylationCaller
+    from hifimeth_amd.synth import read_from_ascii
+    rng = np.random.default_rng(11)
+
+    def read_with(k, L=2400):
+        seq = bytearray(b"A" * L)
+        for i in range(k):
+            seq[300 + 53 * i] = ord("C")   # C A A: a CHH site; 53 apart: its own window, every residue class mod 16 in turn
+        kin = [np.clip(np.rint(rng.gamma(2.0, 12.0, L)), 0, 255).astype(np.uint8) for _ in range(4)]
+        return read_from_ascii(bytes(seq), *kin, name=f"k{k}")
+
+    ks = [1, 15, 16, 17, 33]
+    reads = [read_with(k) for k in ks]
+    for rs, want in [([r], k) for r, k in zip(reads, ks)] + [(reads, sum(ks))]:
+        out = []
+        for impl in (1, 3):
+            with MethylationCaller(contexts="chh", device=0) as m:
+                m.set_option("trunk", 1)
+                m.set_option("tail_impl", impl)
+                out.append(m.call(rs).copy())
+        assert len(out[0]) == len(out[1]) == want, (want, len(out[0]), len(out[1]))
+        assert out[0].tobytes() == out[1].tobytes(), want
+
+
+@pytest.mark.gpu
 def test_human_like_reads_mix_the_per_site_and_the_trunk_path_in_one_engine(oracle, oracle_models):
     """BASELINE.json configs[3] statistics (bench.py --workload human_slice: GC 0.41, CpG depleted to observed / expected 0.24 -> ~1 %
     of the bases): with the default options CpG takes the per-site kernels while CHG and CHH take the dense trunk, in the same engine
