@@ -599,7 +599,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
     e->d_dump.reserve(trunk3_dump_bytes(e->num_cu));
     e->d_edge4.reserve((size_t)max_bases * 2 * C4_CH * sizeof(float));
     e->d_e4row.reserve((size_t)max_bases * sizeof(int32_t));
-    if (e->tail_impl == 3 && e->precision == 1 && (ctx_mask >> CHH & 1)) {   // strip tail: sized for the largest group, before anything is queued
+    if (e->tail_impl == 3 && e->precision >= 1 && (ctx_mask >> CHH & 1)) {   // strip tail: sized for the largest group, before anything is queued
         e->d_mark.reserve(tail_strip_mark_bytes(2 * max_rows));
         e->d_ccnt.reserve(tail_strip_count_bytes(2 * max_rows));
         e->d_order.reserve((size_t)max_bases * sizeof(int32_t));
@@ -687,10 +687,10 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
                                           e->d_e4row.as<int32_t>() + off, e->d_x6.as<uint16_t>(), ph, b->d_logits.as<float>(),
                                           b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu);
                     }
-                } else if (e->tail_impl == 3 && e->precision == 1 && c == CHH) {   // (precision 2's fp16-weight layers live in tail_kernel_r)
+                } else if (e->tail_impl == 3 && e->precision >= 1 && c == CHH) {
                     launch_tail_strip(e->stream, sr, dm.w, maps, n_views, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(), e->d_mark.as<int32_t>(),
                                       e->d_ccnt.as<int32_t>(), e->d_order.as<int32_t>(), e->d_okey.as<int32_t>(), e->d_odst.as<int32_t>(), e->d_x8.as<uint16_t>(),
-                                      b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), b->d_totals.as<int32_t>() + 11, e->num_cu);
+                                      b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), b->d_totals.as<int32_t>() + 11, e->num_cu, e->precision == 2);
                 } else if ((e->tail_impl == 1 || e->tail_impl == 3) && e->precision >= 1)
                     launch_tail_gather_r(e->stream, sr, dm.w, maps, e->d_edge4.as<uint16_t>(), e->d_e4row.as<int32_t>(),
                                          b->d_logits.as<float>(), b->d_p.as<float>(), b->d_ml.as<uint8_t>(), e->num_cu, e->precision == 2);

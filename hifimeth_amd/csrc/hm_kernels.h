@@ -93,11 +93,12 @@ size_t tail_strip_mark_bytes(int64_t map_rows);
 size_t tail_strip_count_bytes(int64_t map_rows);
 void launch_tail_strip(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, int n_views, const uint16_t* edge4,
                        const int32_t* e4row, int32_t* mark, int32_t* cnt, int32_t* order, int32_t* okey, int32_t* odst, uint16_t* x8, float* logits, float* p,
-                       uint8_t* ml, int32_t* pass_count, int grid);   // pass_count (may be null): += the launch's passes of 16 site slots
+                       uint8_t* ml, int32_t* pass_count, int grid, bool w16);   // pass_count (may be null): += the launch's passes of 16 site slots;
+                                                                               // w16: precision 2 (plain fp16 weights in conv8 and fc1)
 // fc1, fc2, softmax over conv8's rows (x8: TAIL_X8_HALVES per site, in list order; dst: list position -> slot in logits / p / ml) -- hm_tail_fc.hip
 size_t tail_fc_x8_bytes(int64_t sites);
 void launch_tail_fc(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const uint16_t* x8, const int32_t* dst, float* logits, float* p,
-                    uint8_t* ml, int grid);
+                    uint8_t* ml, int grid, bool w16);
 void launch_trunk2(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,
                    const uint8_t* bases, const uint32_t* kin, const uint8_t* sctx, const CtxWeights& w,
                    const TrunkMaps& maps, int grid, bool w16, bool waves8 = false);

@@ -40,6 +40,8 @@ struct FcGeo {
 
 }  // namespace
 
+// W16: engine option precision = 2 -- fc1 with plain fp16 weights (w_lo x_hi dropped, the lo plane not fetched), as tail_kernel_r<true>'s
+template <bool W16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void tail_fc_kernel(SiteRange sr, CtxWeights W, float* __restrict__ logits, float* __restrict__ prob, uint8_t* __restrict__ ml,
                     const half_t* __restrict__ x8, const int32_t* __restrict__ dst) {
@@ -62,7 +64,7 @@ void tail_fc_kernel(SiteRange sr, CtxWeights W, float* __restrict__ logits, floa
     }
     // pad columns 64 .. 71 of the operand rows are never read (a k-block ends at channel 63)
 
-    using CF = PCfg<64, 2>;
+    using CF = PCfg<64, 2, !W16>;
     using IF = PInRows<CF, T::RS64, 2, 0, 0, 0>;
     // one stream per tile: the wave's four n-tiles (64 of fc1's 256 outputs) on the tile's 16 sites -- 4 accumulators, 12 MFMAs per
     // k-block, the operand reads three k-blocks ahead (the strip kernel's fc1 ran two n-tiles at a time, reads one block ahead: its
@@ -71,7 +73,7 @@ void tail_fc_kernel(SiteRange sr, CtxWeights W, float* __restrict__ logits, floa
     const half_t* wf8 = reinterpret_cast<const half_t*>(W.wfrag_h[8]);
     TW<4, 4> WF;
     const int ntf[4] = {4 * wave, 4 * wave + 1, 4 * wave + 2, 4 * wave + 3}, colf[4] = {64 * wave, 64 * wave + 16, 64 * wave + 32, 64 * wave + 48};
-    tw_load(wf8, ntf, tid & 63, WF);
+    tw_load<!W16>(wf8, ntf, tid & 63, WF);
     float4 bzf[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bzf[j] = *reinterpret_cast<const float4*>(W.bias[8] + colf[j] + 4 * ((tid & 63) >> 4));
@@ -166,13 +168,14 @@ void tail_fc_kernel(SiteRange sr, CtxWeights W, float* __restrict__ logits, floa
 size_t tail_fc_x8_bytes(int64_t sites) { return (size_t)std::max<int64_t>(sites, 1) * TAIL_X8_HALVES * sizeof(uint16_t); }
 
 void launch_tail_fc(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const uint16_t* x8, const int32_t* dst, float* logits, float* p,
-                    uint8_t* ml, int grid) {
+                    uint8_t* ml, int grid, bool w16) {
     if (sr.cap <= 0) return;
     // two workgroups fit a CU; eight times as many are launched (each loads its 128 KB of weights once for ~ 40 tiles): the dispatcher
     // evens out what a fixed two-per-CU placement would not; with a host-known count no more workgroups than there are tiles
     const int want = HM_FC_GRID_PER_CU * grid;
     const dim3 g(sr.totals ? want : max(1, min((sr.cap + FcGeo::S - 1) / FcGeo::S, want)));
-    hipLaunchKernelGGL(tail_fc_kernel, g, dim3(256), 0, st, sr, w, logits, p, ml, reinterpret_cast<const half_t*>(x8), dst);
+    if (w16) hipLaunchKernelGGL(tail_fc_kernel<true>, g, dim3(256), 0, st, sr, w, logits, p, ml, reinterpret_cast<const half_t*>(x8), dst);
+    else hipLaunchKernelGGL(tail_fc_kernel<false>, g, dim3(256), 0, st, sr, w, logits, p, ml, reinterpret_cast<const half_t*>(x8), dst);
 }
 
 }  // namespace hm

@@ -50,8 +50,7 @@ void tail_kernel_p(HM_TAILP_PARAMS) {
 #else
     constexpr bool FC_IN_KERNEL = false;   // the pass ends with conv8; fc1 .. softmax: tail_fc_kernel (hm_tail_fc.hip)
 #endif
-    constexpr bool W16 = false;   // (plain fp16 weights in conv8 / fc1 -- engine option precision = 2 -- run on tail_kernel_r<true>: a second
-                                  //  instance of THIS kernel, in this file or in one of its own, spilled 9 - 13 registers in one of the two)
+    constexpr bool W16 = false;   // (engine option precision = 2 is the run-time parameter w16: see the body's header)
 #include "hm_tail_p_body.inc"
 }
 // ---- the class sort: sites of a launch in (first map row mod 16, first map row) order ----------------------------------------------------
@@ -173,7 +172,7 @@ size_t tail_strip_count_bytes(int64_t map_rows) { return (size_t)16 * (size_t)((
 
 void launch_tail_strip(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const TrunkMaps& maps, int n_views, const uint16_t* edge4,
                        const int32_t* e4row, int32_t* mark, int32_t* cnt, int32_t* order, int32_t* okey, int32_t* odst, uint16_t* x8, float* logits,
-                       float* p, uint8_t* ml, int32_t* pass_count, int grid) {
+                       float* p, uint8_t* ml, int32_t* pass_count, int grid, bool w16) {
     if (sr.cap <= 0) return;
     const int64_t n_rows = maps.view_rows * n_views;
     const int n_blocks = (int)((n_rows + CS_ROWS - 1) / CS_ROWS);
@@ -185,9 +184,14 @@ void launch_tail_strip(hipStream_t st, const SiteRange& sr, const CtxWeights& w,
     const dim3 g(sr.totals ? grid : max(1, min((sr.cap + PGeo::S - 1) / PGeo::S, grid)));
     hipLaunchKernelGGL(tail_kernel_p, g, dim3(256), 0, st, sr, w, logits, p, ml, reinterpret_cast<const half_t*>(maps.e4),
                             reinterpret_cast<const half_t*>(edge4), order, okey, (int)std::min<int64_t>(n_rows, INT32_MAX), pass_count,
-                            reinterpret_cast<half_t*>(x8));
+                            reinterpret_cast<half_t*>(x8), w16 ? 1 : 0);
 #ifndef HM_TAILP_FC_IN_KERNEL
-    launch_tail_fc(st, sr, w, x8, odst, logits, p, ml, grid);
+    launch_tail_fc(st, sr, w, x8, odst, logits, p, ml, grid, w16);
+#else
+    if (w16) {   // (the A/B build keeps fc1 in the pass with full weights: it has no precision 2)
+        fprintf(stderr, "hifimeth_hip (fcin build): precision 2 is not available with fc1 inside the strip kernel\n");
+        abort();
+    }
 #endif
 }
 

@@ -60,6 +60,6 @@ struct PInStrip {
 
 #define HM_TAILP_PARAMS SiteRange sr, CtxWeights W, float* __restrict__ logits, float* __restrict__ prob, uint8_t* __restrict__ ml, \
                         const half_t* __restrict__ e4, const half_t* __restrict__ edge4, const int32_t* __restrict__ order,      \
-                        const int32_t* __restrict__ okey, int n_rows, int32_t* __restrict__ pass_count, half_t* __restrict__ x8
+                        const int32_t* __restrict__ okey, int n_rows, int32_t* __restrict__ pass_count, half_t* __restrict__ x8, int w16
 
 }  // namespace hm
