@@ -140,6 +140,9 @@ struct PConv {
                 if constexpr (!IA::skip(tile, kb)) {
                     constexpr int sl = (s0 + rslot(b, i)) % NS;
                     const int off = ia.template off<tile, kb>();
+#ifdef HM_XP_NO_READS   // timing ablation (make xp / stampxp): only the first blocks' operands are read, the stream multiplies stale registers
+                    if constexpr (b >= issued(0)) return;
+#endif
                     x[sl] = *reinterpret_cast<const half8*>(in_hi + off);
                     x[(sl + 1) % NS] = *reinterpret_cast<const half8*>(in_lo + off);
                 }
@@ -151,9 +154,22 @@ struct PConv {
             constexpr int g = decltype(g_)::value, a = decltype(a_)::value;
             using G = Grp<g>;
             constexpr int ti = G::acc_tile(a), tile = G::tile(ti), j = G::acc_j(a);
+#if defined(HM_XP_NO_EPI)      // timing ablation: the accumulator is kept alive, nothing is computed from it or stored
+            const f32x4 av = acc[g & 1][a];
+            const float a0_ = av[0], a1_ = av[1], a2_ = av[2], a3_ = av[3];
+            asm volatile("" ::"v"(a0_), "v"(a1_), "v"(a2_), "v"(a3_));
+#elif defined(HM_XP_NO_STORE)  // timing ablation: ReLU + split, no store
+            typename Epi::St est;
+            epi.s0(acc[g & 1][a], est);
+            uint32_t wv[sizeof(est) / 4];
+            __builtin_memcpy(wv, &est, sizeof(est));
+#pragma unroll
+            for (int q = 0; q < (int)(sizeof(est) / 4); ++q) asm volatile("" ::"v"(wv[q]));
+#else
             typename Epi::St est;
             epi.s0(acc[g & 1][a], est);
             epi.template s1<tile>(ncol[j], est);
+#endif
         };
         tstatic_for<0, issued(0)>(reads);
 
