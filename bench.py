@@ -580,13 +580,13 @@ def main():
             k1 = {0: 11, 1: 11, 2: 13}
             edge_mfma = sum(served[c] / 32.0 * edge_pass[k1[c]] for c in range(3))
             # tail_kernel_r, per pass of 8 sites: conv5 7 m-tiles x 6 x 9 x 3, conv6 4 x 6 x 9 x 3, conv7 2 x 4 x 9 x 3, conv8 1 x 4 x 6 x 3, fc1 per
-            # 32 sites 2 x 16 x 4 x 3.  tail_kernel_p (strip tail, CHH), per pass of 16 site slots, zero-padding taps skipped: conv5 (13 x 9 - 6)
-            # k-blocks x 3 x 6, conv6 (7 x 9 - 6) x 3 x 6, conv7 (4 x 9 - 6) x 3 x 4, conv8 (2 x 6 - 2) x 3 x 4; the kernel counts its passes.  fc1 of those
+            # 32 sites 2 x 16 x 4 x 3.  tail_kernel_p (strip tail, CHH), per pass of 16 site slots, zero-padding taps skipped: conv5 DENSE over the strip's rows, (9 row tiles x 9
+            # + 2 site tiles x 6) k-blocks x 3 x 6 (site-major it was (13 x 9 - 6)), conv6 (7 x 9 - 6) x 3 x 6, conv7 (4 x 9 - 6) x 3 x 4, conv8 (2 x 6 - 2) x 3 x 4; the kernel counts its passes.  fc1 of those
             # sites runs in tail_fc_kernel on full tiles of 16 sites in list order: 16 n-tiles x 4 k-blocks x 3 per tile (the ragged last tile of a
             # launch -- one in ~ 160 000 -- is not counted)
             pr8 = 2 if args.precision == 2 else 3   # products per k-block in conv8 and fc1 (precision 2: plain fp16 weights there)
             tail_r_site = (7 * 6 * 27 + 4 * 6 * 27 + 2 * 4 * 27 + 4 * 6 * pr8) / 8.0 + 2 * 16 * 4 * pr8 / 32.0
-            strip_pass = (13 * 9 - 6) * 18 + (7 * 9 - 6) * 18 + (4 * 9 - 6) * 12 + (2 * 6 - 2) * 4 * pr8
+            strip_pass = (9 * 9 + 2 * 6) * 18 + (7 * 9 - 6) * 18 + (4 * 9 - 6) * 12 + (2 * 6 - 2) * 4 * pr8
             fc_tile = 16 * 4 * pr8
             strip_passes = int(tm.get("tail_strip_passes", 0))
             strip_mfma = strip_passes * strip_pass + (served[2] / 16.0 * fc_tile if strip_passes > 0 else 0.0)
