@@ -205,7 +205,7 @@ struct hm_engine {
     DevBuf d_x6;                // split tail: conv6's rows of one launch (hm_tail_s.hip)
     DevBuf d_mark, d_ccnt, d_order, d_okey;  // strip tail (hm_tail_p.hip): per-map-row marks, class counters, the class-sorted site order and its keys
     DevBuf d_odst;              // strip tail: list position -> the site's slot in the batch's result arrays (tail_fc_kernel's stores)
-    DevBuf d_x8;                // conv8's rows of a launch's sites on their way from the strip tail kernel to tail_fc_kernel (512 B per site)
+    DevBuf d_x8;                // the rows of a launch's sites on their way from the strip tail kernel to its second kernel (TAIL_STRIP_HANDOVER_BYTES per site)
     DevBuf d_dump;              // sliding-window trunk: where a warm-up step's conv4 rows go (hm_trunk3.hip)
     int64_t x6_sites = 0;       // the site count d_x6's plane stride was laid out for
 
@@ -217,8 +217,8 @@ namespace {
 
 // Device bytes per base of a read group: E1..E3 maps (2 views x 512 B each), E4 (2 x 384 B), the sites' edge rows (768 B) and map-row
 // numbers, row lists -- times the 25 % head-room DevBuf::reserve adds.
-constexpr int64_t GROUP_BYTES_PER_BASE = (3 * 2 * 512 + 2 * 384 + 768 + 4 + 8 + 2 * 4 + 8 + 4 + 512) * 5 / 4;  // (+ the strip tail's marks per map row, its sorted order and
-                                                                                                            //  conv8's rows for tail_fc_kernel, sized per base: a base is at most one site)
+constexpr int64_t GROUP_BYTES_PER_BASE = (3 * 2 * 512 + 2 * 384 + 768 + 4 + 8 + 2 * 4 + 8 + 4 + TAIL_STRIP_HANDOVER_BYTES) * 5 / 4;  // (+ the strip tail's marks per map row, its sorted order and
+                                                                                                            //  the rows handed to its second kernel, sized per base: a base is at most one site)
 
 int64_t effective_group_bases(hm_engine* e) {
     if (e->group_bases > 0) return e->group_bases;
@@ -605,7 +605,7 @@ void run_trunk_path(hm_batch* b, std::vector<TimedSpan>* spans, int ctx_mask) {
         e->d_order.reserve((size_t)max_bases * sizeof(int32_t));
         e->d_okey.reserve((size_t)max_bases * sizeof(int32_t));
         e->d_odst.reserve((size_t)max_bases * sizeof(int32_t));
-        e->d_x8.reserve(tail_fc_x8_bytes(max_bases));
+        e->d_x8.reserve(tail_strip_handover_bytes(max_bases));
     }
     if (!e->d_zeros.p) {
         e->d_zeros.reserve(1024);
