@@ -586,8 +586,8 @@ def main():
             # launch -- one in ~ 160 000 -- is not counted)
             pr8 = 2 if args.precision == 2 else 3   # products per k-block in conv8 and fc1 (precision 2: plain fp16 weights there)
             tail_r_site = (7 * 6 * 27 + 4 * 6 * 27 + 2 * 4 * 27 + 4 * 6 * pr8) / 8.0 + 2 * 16 * 4 * pr8 / 32.0
-            strip_pass = (9 * 9 + 2 * 6) * 18 + (7 * 9 - 6) * 18          # tail_kernel_p: conv5 (dense over the strip's rows) + conv6
-            fc_tile = (4 * 9 - 6) * 12 + (2 * 6 - 2) * 4 * pr8 + 16 * 4 * pr8   # tail_head_p_kernel, per full tile of 16 sites: conv7 + conv8 + fc1
+            strip_pass = (9 * 9 + 2 * 6) * 18 + (7 * 9 - 6) * 18 + (4 * 9 - 6) * 12 + (2 * 6 - 2) * 4 * pr8
+            fc_tile = 16 * 4 * pr8
             strip_passes = int(tm.get("tail_strip_passes", 0))
             strip_mfma = strip_passes * strip_pass + (served[2] / 16.0 * fc_tile if strip_passes > 0 else 0.0)
             tail_mfma = sum(served[c] * tail_r_site for c in range(3) if not (c == 2 and strip_passes > 0)) + strip_mfma
@@ -600,8 +600,8 @@ def main():
                          "mfma_per_site": {"K1=11": edge_pass[11] / 32.0, "K1=13": edge_pass[13] / 32.0}},
                 "tail": {"mfma": tail_mfma, "ms": tail_ms_t, "executed": tf(tail_mfma, tail_ms_t), "frac": tf(tail_mfma, tail_ms_t) / peak, "share_of_device_ms": tail_ms_t / dev_ms,
                          "strip_tail_passes": strip_passes, "strip_tail_sites_per_pass": served[2] / strip_passes if strip_passes else None,
-                         "mfma_per_site": {"tail_kernel_r": tail_r_site, "tail_kernel_p + tail_head_p_kernel": strip_mfma / served[2] if strip_passes and served[2] else None},
-                         "note": "tail_ms of the strip tail = its class sort (memset + 4 small kernels per launch) + tail_kernel_p (conv5, conv6) + tail_head_p_kernel (conv7 .. softmax)"},
+                         "mfma_per_site": {"tail_kernel_r": tail_r_site, "tail_kernel_p + tail_fc_kernel": strip_mfma / served[2] if strip_passes and served[2] else None},
+                         "note": "tail_ms of the strip tail = its class sort (memset + 4 small kernels per launch) + tail_kernel_p (conv5 .. conv8) + tail_fc_kernel (fc1, fc2, softmax)"},
                 # this rank's device: all MFMAs of the timed region over its WALL time (copies, staging and scanner kernels included)
                 "whole_device": {"mfma": n_mfma + edge_mfma + tail_mfma, "executed_over_timed_region": tf(n_mfma + edge_mfma + tail_mfma, dt * 1e3),
                                  "frac_over_timed_region": tf(n_mfma + edge_mfma + tail_mfma, dt * 1e3) / peak},

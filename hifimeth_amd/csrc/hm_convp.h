@@ -70,19 +70,6 @@ struct EpiX8 {
         *reinterpret_cast<half4*>(g + TAIL_X8_HALVES / 2 + TILE * 64 + col) = s.l;
     }
 };
-// conv6's rows on their way to tail_head_p_kernel (hm_tail_head.hip): ReLU + split -> global, a site's 2 688 bytes = [hi: position * 96 + channel | lo];
-// `g` is this lane's: xh + (the site's list position) * TAIL_XH_HALVES + 4 * lk
-struct EpiX6 {
-    static constexpr int NV0 = 6, NV1 = 1, NW = 2, WMASK = 0x040;
-    struct St { half4 h, l; };
-    half_t* g;
-    __device__ __forceinline__ void s0(const f32x4& acc, St& s) const { split4(acc, s.h, s.l); }
-    template <int TILE>
-    __device__ __forceinline__ void s1(int col, const St& s) const {
-        *reinterpret_cast<half4*>(g + TILE * 96 + col) = s.h;
-        *reinterpret_cast<half4*>(g + TAIL_XH_HALVES / 2 + TILE * 96 + col) = s.l;
-    }
-};
 // fc1: ReLU, fp32 h[site][8 parts of 32, HPS floats apart] for the VALU fc2; `out` is this lane's: h + li * (8 HPS) + 4 * lk
 template <int HPS>
 struct EpiFc1P {

@@ -130,13 +130,7 @@ struct CtxWeights {
 constexpr int C4_LEN = 25, C4_CH = 96;          // conv4 output = hand-off between front and tail kernels
 constexpr int ACT4_FLOATS = C4_LEN * C4_CH;      // 2400 floats / site
 constexpr int TAIL_SITES = 8;                    // sites stacked along M in the tail kernel
-// the strip tail (hm_tail_p.hip) hands its sites over to a second kernel: 1 = behind conv6 (tail_head_p_kernel, hm_tail_head.hip: conv7 .. softmax;
-// 2 688 B per site), 0 = behind conv8 (tail_fc_kernel, hm_tail_fc.hip: fc1 .. softmax; 512 B per site)
-#ifndef HM_TAILP_SPLIT6
-#define HM_TAILP_SPLIT6 1
-#endif
-constexpr int TAIL_XH_HALVES = 2 * 7 * 96;       // conv6's output of a site on its way to tail_head_p_kernel: [hi: 7 positions x 96 channels | lo]
-constexpr int TAIL_STRIP_HANDOVER_BYTES = HM_TAILP_SPLIT6 ? TAIL_XH_HALVES * 2 : 512;
+constexpr int TAIL_STRIP_HANDOVER_BYTES = 512;  // what the strip tail kernel hands to tail_fc_kernel per site (conv8's rows, TAIL_X8_HALVES)
 constexpr int TAIL_X8_HALVES = 256;              // conv8's output of a site on its way to tail_fc_kernel: [hi: 2 positions x 64 channels | lo] (hm_tail_fc.hip)
 constexpr int TAILP_STRIP = 144;                 // strip tail (hm_tail_p.hip): lattice rows (16 map rows apart) of E4 a pass of 16 sites shares in LDS
 

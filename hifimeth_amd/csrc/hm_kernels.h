@@ -97,10 +97,7 @@ void launch_tail_strip(hipStream_t st, const SiteRange& sr, const CtxWeights& w,
                                                                                // w16: precision 2 (plain fp16 weights in conv8 and fc1)
 // fc1, fc2, softmax over conv8's rows (x8: TAIL_X8_HALVES per site, in list order; dst: list position -> slot in logits / p / ml) -- hm_tail_fc.hip
 size_t tail_fc_x8_bytes(int64_t sites);
-// conv7 .. softmax over conv6's rows (xh: TAIL_XH_HALVES per site, in list order) -- hm_tail_head.hip; which of the two follows the strip kernel: HM_TAILP_SPLIT6
 size_t tail_strip_handover_bytes(int64_t sites);
-void launch_tail_head_p(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const uint16_t* xh, const int32_t* dst, float* logits, float* p,
-                        uint8_t* ml, int grid, bool w16);
 void launch_tail_fc(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const uint16_t* x8, const int32_t* dst, float* logits, float* p,
                     uint8_t* ml, int grid, bool w16);
 void launch_trunk2(hipStream_t st, int k1, const TrunkTile* tiles, int n_tiles, int n_views, int ctx, const RInfo* rinfo,

@@ -165,10 +165,7 @@ void tail_fc_kernel(SiteRange sr, CtxWeights W, float* __restrict__ logits, floa
     }
 }
 
-#ifndef HM_XP_X8_SCALE   // (timing experiments that send more than conv8's rows through the buffer)
-#define HM_XP_X8_SCALE 1
-#endif
-size_t tail_fc_x8_bytes(int64_t sites) { return (size_t)std::max<int64_t>(sites, 1) * TAIL_X8_HALVES * sizeof(uint16_t) * HM_XP_X8_SCALE; }
+size_t tail_fc_x8_bytes(int64_t sites) { return (size_t)std::max<int64_t>(sites, 1) * TAIL_X8_HALVES * sizeof(uint16_t); }
 
 void launch_tail_fc(hipStream_t st, const SiteRange& sr, const CtxWeights& w, const uint16_t* x8, const int32_t* dst, float* logits, float* p,
                     uint8_t* ml, int grid, bool w16) {

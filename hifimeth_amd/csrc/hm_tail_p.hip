@@ -45,9 +45,6 @@ namespace hm {
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void tail_kernel_p(HM_TAILP_PARAMS) {
-#if defined(HM_TAILP_FC_IN_KERNEL) && HM_TAILP_SPLIT6
-#error "make fcin builds the strip kernel that ends with fc2: it needs -DHM_TAILP_SPLIT6=0"
-#endif
 #ifdef HM_TAILP_FC_IN_KERNEL
     constexpr bool FC_IN_KERNEL = true;    // A/B build (make HM_TAILP_FC_IN_KERNEL=1): fc1, fc2, softmax per pass, as before the split
 #else
@@ -189,9 +186,7 @@ void launch_tail_strip(hipStream_t st, const SiteRange& sr, const CtxWeights& w,
     hipLaunchKernelGGL(tail_kernel_p, g, dim3(256), 0, st, sr, w, logits, p, ml, reinterpret_cast<const half_t*>(maps.e4),
                             reinterpret_cast<const half_t*>(edge4), order, okey, (int)std::min<int64_t>(n_rows, INT32_MAX), pass_count,
                             reinterpret_cast<half_t*>(x8), w16 ? 1 : 0);
-#if HM_TAILP_SPLIT6
-    launch_tail_head_p(st, sr, w, x8, odst, logits, p, ml, grid, w16);
-#elif !defined(HM_TAILP_FC_IN_KERNEL)
+#ifndef HM_TAILP_FC_IN_KERNEL
     launch_tail_fc(st, sr, w, x8, odst, logits, p, ml, grid, w16);
 #else
     if (w16) {   // (the A/B build keeps fc1 in the pass with full weights: it has no precision 2)
